@@ -1,0 +1,153 @@
+/*
+ * ttnet.h -- C ABI of the MI355X-native TTNet inference path (libttnet.so).
+ *
+ * This is the drop-in boundary for ONE path of Anonymousijcai2024ttnet/scale_imagenet: the
+ * eval-mode forward() of the TTNet ImageNet classifiers.  The reference has no FFI (it is
+ * 100 % PyTorch), so each entry point below names the reference interface it replaces
+ * (file:line under the upstream repository) and INTEGRATION.md shows the ctypes stub a
+ * maintainer adds to the reference's nn.Module to call it.
+ *
+ * Conventions
+ *   - plain C types only; device pointers are raw HIP device addresses; `stream` is a
+ *     hipStream_t passed as void* (NULL = the null stream).
+ *   - every function returns 0 on success or a negative ttnet_status; the message for the
+ *     last failure on the calling thread is ttnet_last_error().
+ *   - a plan is bound to one device; calls on one plan are serialised by the caller;
+ *     different plans may run concurrently on different streams.
+ *   - the library allocates only inside ttnet_plan_create / _finalize (weights, truth
+ *     tables, activation workspace for `max_batch` images); ttnet_forward allocates nothing
+ *     and never synchronises, so it can be captured into a hipGraph.
+ *   - there is no CPU fallback: without a HIP device every compute entry point fails.
+ *
+ * Packed activation layouts (all little-endian, LSB first)
+ *   rows  ("RP"): uint64 [N][C][H]      bit x of word (n,c,y) is pixel (y,x); W <= 60
+ *   chans ("CP"): uint16 [N][H][W][C/16] bit k of word (n,y,x,q) is channel 16q+k
+ */
+#ifndef TTNET_H
+#define TTNET_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ttnet_plan ttnet_plan;
+typedef struct ttnet_comm ttnet_comm;
+
+typedef enum ttnet_status {
+  TTNET_OK = 0,
+  TTNET_E_INVALID = -1,      /* bad argument (NULL, shape, unknown key, batch > max_batch) */
+  TTNET_E_STATE = -2,        /* call out of order (forward before finalize, missing tensor) */
+  TTNET_E_HIP = -3,          /* a HIP runtime call failed; message carries hipGetErrorString */
+  TTNET_E_UNSUPPORTED = -4,  /* geometry this build has no kernel for */
+  TTNET_E_NOMEM = -5
+} ttnet_status;
+
+typedef enum ttnet_dtype { TTNET_F32 = 0, TTNET_I64 = 1, TTNET_U8 = 2, TTNET_U16 = 3, TTNET_U64 = 4 } ttnet_dtype;
+
+typedef enum ttnet_variant {
+  TTNET_SMALL = 0,   /* models/TT_general_imagenet_v2_small.py:151  TT_vf_19lv3_imgnet_small  */
+  TTNET_XSMALL = 1,  /* models/TT_general_imagenet_v2_xsmall.py:151 TT_vf_19lv3_imgnet_xsmall */
+  TTNET_FULL = 2     /* models/TT_general_imagenet_v2.py:139        TT_vf_19lv3_imgnet        */
+} ttnet_variant;
+
+/* The constructor arguments of the reference model (args.nfilter / tfilter / layers,
+ * models/TT_general_imagenet_v2_small.py:154-181; main.py:47-50) plus what the reference
+ * discovers with a dry run on torch.rand(1,3,224,224) (:199-207): the input size. */
+typedef struct ttnet_net_desc {
+  int32_t variant;     /* ttnet_variant */
+  int32_t nfilter;     /* main.py:47, default 8 */
+  int32_t tfilter;     /* main.py:48, default 8 */
+  int32_t layers;      /* main.py:50, default 1 */
+  int32_t image_h;     /* 224 */
+  int32_t image_w;     /* 224 */
+  int32_t max_batch;   /* workspace is sized for this many images per forward */
+  int32_t reserved;
+} ttnet_net_desc;
+
+/* Replaces TT_vf_19lv3_imgnet_small.__init__ / make_small_network
+ * (models/TT_general_imagenet_v2_small.py:154-203): fixes the geometry, allocates device
+ * storage for the 174 state tensors and the activation workspace. */
+int ttnet_plan_create(const ttnet_net_desc *desc, int device, ttnet_plan **out);
+
+/* Replaces nn.Module.load_state_dict (main.py:220-222): hands the plan one state_dict
+ * entry under its reference key, e.g. "features.4.Block_conv1.conv1.weight".  A leading
+ * "module." (DataParallel / DDP checkpoints, main.py:181-192) is accepted and stripped.
+ * `ptr` may be a host or a device pointer (on_device != 0); the bytes are copied.
+ * num_batches_tracked and grad_scale entries are accepted and ignored (eval mode never
+ * reads them).  Unknown keys and shape / dtype mismatches are TTNET_E_INVALID, as strict
+ * load_state_dict would raise. */
+int ttnet_plan_set_tensor(ttnet_plan *plan, const char *key, const void *ptr,
+                          const int64_t *shape, int ndim, int dtype, int on_device);
+
+/* Derived state, rebuilt after the tensors change: folds every BatchNorm, enumerates every
+ * binarised Block_TT into its truth table on the GPU (float64, exact erf; the enumeration
+ * convention of Block_TT.get_TT_block_all_filter, models/TT_FHE_SMALL.py:322-342), builds
+ * the float table of the last block, permutes lin1 to the feature order of the device
+ * kernels.  Fails with TTNET_E_STATE if a required tensor was never set. */
+int ttnet_plan_finalize(ttnet_plan *plan, void *stream);
+
+/* Replaces SeqBinModelHelper.forward (models/model_utils/netbin.py:703-708), i.e.
+ * `outputs = model(inputs)` at main.py:261 in eval mode under no_grad.
+ *   x_dev      float32 [n,3,image_h,image_w] NCHW, contiguous, on the plan's device
+ *   logits_dev float32 [n,1000]
+ * Asynchronous on `stream`. */
+int ttnet_forward(ttnet_plan *plan, const float *x_dev, int64_t n, float *logits_dev, void *stream);
+
+/* Same, starting from the binarised stem output (features[3], netbin.py:193) given as
+ * row-packed bits uint64 [n][p][56]; used by the parity tests to separate the integer
+ * gate path (bit exact) from the float stem (exact except at near ties). */
+int ttnet_forward_from_stem_bits(ttnet_plan *plan, const uint64_t *rows_dev, int64_t n,
+                                 float *logits_dev, void *stream);
+
+/* Parity taps: copies a stage of the LAST forward on this plan to `dst` (host pointer
+ * unless on_device).  Stages: "features.3", "features.4", "features.5" (row-packed uint64
+ * [n][C][H]), "features.<b>.out1".."out4" (row-packed, after the branch padding),
+ * "flatten" (float32 [n][fcsize] in the reference's C-major order), "stem.pre"
+ * is not kept.  Synchronises `stream`.  Replaces the reference's debug attributes
+ * Block_TT.input_layer / output_layer (models/TT_FHE_SMALL.py:310,319). */
+int ttnet_read_stage(ttnet_plan *plan, const char *stage, int64_t n, void *dst, size_t dst_bytes,
+                     int on_device, void *stream);
+
+/* Truth-table export / import in the reference's canonical order
+ * (Block_TT.get_TT_block_all_filter, models/TT_FHE_SMALL.py:322-342): for Block_TT `name`
+ * (e.g. "features.4.Block_conv3"), `bits` is uint8 [groups][2^n][cout_per_group] with
+ * entry index = the pattern read MSB first over (c_in_group, kh, kw).  get copies the
+ * table the plan built; set replaces it (e.g. with truth tables published alongside a
+ * checkpoint, README.md:22).  For the last (float) block the element type is float32. */
+int ttnet_plan_get_table(ttnet_plan *plan, const char *name, void *dst_host, size_t dst_bytes);
+int ttnet_plan_set_table(ttnet_plan *plan, const char *name, const void *src_host, size_t src_bytes);
+
+/* Integer facts about the plan: "fcsize", "n_classes", "n_state_tensors", "max_batch",
+ * "near_ties:<block_tt name>" (entries with |pre-activation| < 1e-5 found while building
+ * that table), "table_bytes", "workspace_bytes". */
+int ttnet_plan_query(ttnet_plan *plan, const char *what, int64_t *out);
+
+/* Device time of the kernels of the last forward, measured with HIP events on the stream
+ * the kernels were launched on (enable with ttnet_plan_set_profiling).  names/ms are
+ * arrays of capacity `cap`; returns the number of entries.  Synchronises. */
+int ttnet_plan_set_profiling(ttnet_plan *plan, int enabled);
+int ttnet_plan_last_timings(ttnet_plan *plan, const char **names, float *ms, int cap);
+
+void ttnet_plan_destroy(ttnet_plan *plan);
+
+/* Multi-GPU: the path shards by image (eval BatchNorm uses running statistics; nothing
+ * crosses samples).  The only exchange is the gather of logits that
+ * torch.nn.DataParallel.gather performs on GPU 0 in the reference (main.py:192).  One
+ * process per GPU; `unique_id` is the 128-byte ncclUniqueId from ttnet_comm_unique_id on
+ * rank 0, distributed by the caller (e.g. through its torch.distributed store). */
+int ttnet_comm_unique_id(void *id128);
+int ttnet_comm_create(const void *id128, int rank, int world, int device, ttnet_comm **out);
+int ttnet_allgather_logits(ttnet_comm *comm, const float *local_dev, int64_t n_local, int64_t n_classes,
+                           float *all_dev, void *stream);
+void ttnet_comm_destroy(ttnet_comm *comm);
+
+const char *ttnet_last_error(void);
+const char *ttnet_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TTNET_H */

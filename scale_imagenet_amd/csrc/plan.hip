@@ -1,0 +1,912 @@
+// libttnet.so -- plan object and the C ABI of include/ttnet.h.
+//
+// Host-side counterpart of the reference's model object (construction, load_state_dict,
+// forward dispatch; models/TT_general_imagenet_v2_small.py:151-207,
+// models/model_utils/netbin.py:703-708).  No torch types, no CPU compute path: every
+// arithmetic step of forward() is a HIP kernel from stem.hip / gate.hip / head.hip, and the
+// derived tables are built by lut_build.hip.  Host code here only folds BatchNorm
+// parameters (a few thousand scalars, float64) and moves bytes.
+
+#include <dlfcn.h>
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+#include <map>
+#include <memory>
+
+#include "ttnet_common.h"
+
+namespace ttnet {
+
+static thread_local char g_err[1024] = "";
+
+void set_error(const char *fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+namespace {
+
+constexpr double kBnEps = 1e-5;   // nn.BatchNorm2d / BatchNorm1d default
+
+struct Tensor {
+  std::vector<int64_t> shape;
+  int dtype = TTNET_F32;
+  void *dev = nullptr;
+  size_t bytes = 0;
+  bool set = false;
+  bool required = true;
+};
+
+struct BlockTT {
+  BlockGeom g;
+  std::vector<uint8_t> perm;     // internal index bit p -> canonical input column
+  uint8_t *perm_dev = nullptr;
+  double *s1 = nullptr, *t1 = nullptr, *s2 = nullptr, *t2 = nullptr;
+  void *table = nullptr;         // internal layout
+  unsigned *near_dev = nullptr;
+  int64_t near_ties = -1;
+  bool user_table = false;
+};
+
+struct MultiHead {
+  std::string name;
+  int C = 0, H = 0, W = 0, Ho = 0, Wo = 0, off34 = 0, stride = 2;
+  bool last = false;
+  BlockTT c1, c2, c3, cf;
+  uint16_t *o[4] = {nullptr, nullptr, nullptr, nullptr};
+};
+
+struct Timing {
+  const char *name;
+  hipEvent_t e0, e1;
+};
+
+size_t dtype_size(int dt) {
+  switch (dt) {
+    case TTNET_F32: return 4;
+    case TTNET_I64: return 8;
+    case TTNET_U8: return 1;
+    case TTNET_U16: return 2;
+    case TTNET_U64: return 8;
+  }
+  return 0;
+}
+
+}  // namespace
+}  // namespace ttnet
+
+using namespace ttnet;
+
+struct ttnet_plan {
+  ttnet_net_desc desc{};
+  int device = 0;
+  int p = 0;
+  int n_classes = 1000, inter = 1000, fcsize = 0;
+  int featC = 0, featPP = 0;        // last block: channels, pooled pixels per channel
+  std::string head;
+  std::vector<MultiHead> blocks;
+  std::map<std::string, Tensor> tensors;
+  std::vector<std::string> key_order;
+  bool finalized = false;
+
+  // stem
+  float *stem_wt = nullptr, *stem_scale = nullptr, *stem_shift = nullptr;
+  // activations: x_rp[i] / x_cp[i] = input of block i
+  std::vector<uint64_t *> x_rp;
+  std::vector<uint16_t *> x_cp;
+  float *feat = nullptr;
+  // head
+  float *w1p = nullptr, *bn_scale = nullptr, *bn_shift = nullptr, *part = nullptr, *mid = nullptr;
+  size_t part_elems = 0;
+  size_t table_bytes = 0, workspace_bytes = 0;
+  int64_t last_n = 0;
+
+  bool profiling = false;
+  std::vector<Timing> timings;
+  size_t timing_used = 0;
+
+  std::vector<void *> owned;        // everything hipMalloc'ed, freed in destroy
+};
+
+namespace {
+
+template <typename T>
+int dev_alloc(ttnet_plan *pl, T **out, size_t count, bool zero, size_t *account = nullptr) {
+  void *ptr = nullptr;
+  const size_t bytes = std::max<size_t>(count * sizeof(T), 16);
+  hipError_t e = hipMalloc(&ptr, bytes);
+  if (e != hipSuccess) {
+    set_error("hipMalloc(%zu bytes) failed: %s", bytes, hipGetErrorString(e));
+    return TTNET_E_NOMEM;
+  }
+  if (zero) TT_HIP(hipMemset(ptr, 0, bytes));
+  pl->owned.push_back(ptr);
+  if (account) *account += bytes;
+  *out = (T *)ptr;
+  return TTNET_OK;
+}
+
+void add_tensor(ttnet_plan *pl, const std::string &key, std::vector<int64_t> shape, int dtype, bool required) {
+  Tensor t;
+  t.shape = std::move(shape);
+  t.dtype = dtype;
+  size_t n = 1;
+  for (auto d : t.shape) n *= (size_t)d;
+  t.bytes = n * dtype_size(dtype);
+  t.required = required;
+  pl->tensors[key] = t;
+  pl->key_order.push_back(key);
+}
+
+void add_bn(ttnet_plan *pl, const std::string &prefix, int c) {
+  add_tensor(pl, prefix + ".weight", {c}, TTNET_F32, true);
+  add_tensor(pl, prefix + ".bias", {c}, TTNET_F32, true);
+  add_tensor(pl, prefix + ".running_mean", {c}, TTNET_F32, true);
+  add_tensor(pl, prefix + ".running_var", {c}, TTNET_F32, true);
+  add_tensor(pl, prefix + ".num_batches_tracked", {}, TTNET_I64, false);
+}
+
+void add_block_tt(ttnet_plan *pl, const BlockGeom &g) {
+  const int mid = 8 * g.in_planes;
+  add_tensor(pl, g.name + ".conv1.weight", {mid, g.cin_g(), g.kh, g.kw}, TTNET_F32, true);
+  add_bn(pl, g.name + ".bn1", mid);
+  add_tensor(pl, g.name + ".conv2.weight", {g.out_planes, mid / g.groups, 1, 1}, TTNET_F32, true);
+  add_bn(pl, g.name + ".bn2", g.out_planes);
+  add_tensor(pl, g.name + ".act.grad_scale", {}, TTNET_F32, false);
+}
+
+BlockGeom make_geom(const std::string &name, int in_planes, int out_planes, int kh, int kw, int stride, int pad,
+                    int groups, bool last) {
+  BlockGeom g;
+  g.name = name; g.in_planes = in_planes; g.out_planes = out_planes; g.kh = kh; g.kw = kw;
+  g.stride = stride; g.pad = pad; g.groups = groups; g.last = last;
+  return g;
+}
+
+// Geometry of the network (mirrors make_small_network,
+// models/TT_general_imagenet_v2_small.py:159-203, and the shape-keyed branch padding of
+// the block forward, :98-139).
+int build_geometry(ttnet_plan *pl) {
+  const ttnet_net_desc &d = pl->desc;
+  int kh = 4, kw = 4, pad = 2, gsize = 16;
+  if (d.variant == TTNET_SMALL) {
+  } else if (d.variant == TTNET_XSMALL) {
+    kh = kw = 2; pad = 1; gsize = 4;
+    set_error("variant xsmall (fan-in 4) has no gate kernels in this build yet");
+    return TTNET_E_UNSUPPORTED;
+  } else if (d.variant == TTNET_FULL) {
+    set_error("variant full (fan-in 30) cannot be a flat truth table (2^30 entries per output bit); "
+              "its direct-arithmetic kernels are not built yet");
+    return TTNET_E_UNSUPPORTED;
+  } else {
+    set_error("unknown variant %d", d.variant);
+    return TTNET_E_INVALID;
+  }
+  if (d.image_h != 224 || d.image_w != 224) {
+    set_error("only 224x224 inputs are supported (got %dx%d)", d.image_h, d.image_w);
+    return TTNET_E_UNSUPPORTED;
+  }
+  if (d.nfilter < 1 || d.tfilter < 1 || d.max_batch < 1) {
+    set_error("nfilter, tfilter and max_batch must be positive");
+    return TTNET_E_INVALID;
+  }
+  const int p = d.nfilter * d.tfilter;
+  pl->p = p;
+  if (p % 16) {
+    set_error("p = nfilter*tfilter = %d must be a multiple of 16", p);
+    return TTNET_E_UNSUPPORTED;
+  }
+  std::vector<int> cfg;
+  switch (d.layers) {   // all stride 2 (:172-177)
+    case 0: cfg = {p, 2 * p}; break;
+    case 1: cfg = {p, 2 * p, 4 * p}; break;
+    case 2: cfg = {p, 2 * p, 4 * p, 8 * p}; break;
+    default:
+      set_error("--layers %d (stride-1 blocks) is not supported yet", d.layers);
+      return TTNET_E_UNSUPPORTED;
+  }
+  add_tensor(pl, "features.1.weight", {p, 3, 7, 7}, TTNET_F32, true);
+  add_bn(pl, "features.2", p);
+  add_tensor(pl, "features.3.grad_scale", {}, TTNET_F32, false);
+
+  int h = 56, w = 56, in_planes = p;
+  for (size_t i = 0; i < cfg.size(); ++i) {
+    MultiHead mh;
+    mh.name = "features." + std::to_string(4 + i);
+    const int out_planes = cfg[i];
+    mh.last = (out_planes == cfg.back());
+    mh.C = in_planes; mh.H = h; mh.W = w;
+    const int ho = (h + 2 * pad - kh) / 2 + 1, wo = (w + 2 * pad - kw) / 2 + 1;
+    // branch padding keyed by the input width (:98-139): out3/out4 are floor(h/2) wide
+    if (w == 56) mh.off34 = 1;                       // pad0 = ZeroPad2d((1,0,1,0))
+    else if (w == 29 || w == 15 || w == 8 || w == 16 || w == 30) mh.off34 = 0;   // pad2 = (0,1,0,1)
+    else {
+      set_error("%s: no branch-padding rule for width %d", mh.name.c_str(), w);
+      return TTNET_E_UNSUPPORTED;
+    }
+    if (h / 2 + 1 != ho || w / 2 + 1 != wo || h != w) {
+      set_error("%s: branch shapes do not line up (%dx%d -> %dx%d)", mh.name.c_str(), h, w, ho, wo);
+      return TTNET_E_UNSUPPORTED;
+    }
+    mh.Ho = ho; mh.Wo = wo;
+    if (in_planes % gsize) {
+      set_error("in_channels must be divisible by groups (in_planes=%d, group size %d)", in_planes, gsize);
+      return TTNET_E_INVALID;
+    }
+    mh.c1.g = make_geom(mh.name + ".Block_conv1", in_planes, in_planes, kh, kw, 2, pad, in_planes, false);
+    mh.c2.g = make_geom(mh.name + ".Block_conv2", in_planes, in_planes, kh, kw, 2, pad, in_planes, false);
+    mh.c3.g = make_geom(mh.name + ".Block_conv3", in_planes, in_planes, 1, 1, 1, 0, in_planes / gsize, false);
+    const int cf_out = mh.last ? 4 * in_planes : 2 * out_planes;
+    mh.cf.g = make_geom(mh.name + ".Block_convf", 4 * in_planes, cf_out, 1, 1, 1, 0, 4 * in_planes / gsize, mh.last);
+    add_block_tt(pl, mh.c1.g);
+    add_block_tt(pl, mh.c2.g);
+    add_block_tt(pl, mh.c3.g);
+    add_tensor(pl, mh.name + ".act.grad_scale", {}, TTNET_F32, false);
+    add_block_tt(pl, mh.cf.g);
+    // internal index orders
+    for (BlockTT *b : {&mh.c1, &mh.c2, &mh.c3}) {
+      b->perm.resize(b->g.nbits());
+      for (int q = 0; q < b->g.nbits(); ++q) b->perm[q] = (uint8_t)q;
+    }
+    mh.cf.perm.resize(16);
+    for (int br = 0; br < 4; ++br)
+      for (int cl = 0; cl < 4; ++cl) mh.cf.perm[4 * br + cl] = (uint8_t)(4 * cl + br);   // channel 4c+branch
+    pl->blocks.push_back(mh);
+    h = ho; w = wo;
+    in_planes = 2 * out_planes;
+  }
+  const MultiHead &lb = pl->blocks.back();
+  pl->featC = lb.cf.g.out_planes;
+  pl->featPP = (lb.Ho / 2) * (lb.Wo / 2);
+  pl->fcsize = pl->featC * pl->featPP;
+  pl->head = "features." + std::to_string(4 + cfg.size() + 2);
+  add_tensor(pl, pl->head + ".lin1.weight", {pl->inter, pl->fcsize}, TTNET_F32, true);
+  add_bn(pl, pl->head + ".BN2", pl->inter);
+  add_tensor(pl, pl->head + ".lin2.weight", {pl->n_classes, pl->inter}, TTNET_F32, true);
+  add_tensor(pl, pl->head + ".lin2.bias", {pl->n_classes}, TTNET_F32, true);
+  return TTNET_OK;
+}
+
+int gemm_splits(int m, int n, int k) {
+  const int tiles = ((m + 63) / 64) * ((n + 63) / 64);
+  int s = 1024 / tiles;
+  s = std::max(1, std::min(s, 64));
+  s = std::min(s, std::max(1, k / 128));
+  return s;
+}
+
+int allocate(ttnet_plan *pl) {
+  const int nb = pl->desc.max_batch;
+  size_t *ws = &pl->workspace_bytes, *tb = &pl->table_bytes;
+  for (auto &kv : pl->tensors) TT_TRY(dev_alloc(pl, (uint8_t **)&kv.second.dev, kv.second.bytes, true));
+  TT_TRY(dev_alloc(pl, &pl->stem_wt, (size_t)147 * pl->p, false));
+  TT_TRY(dev_alloc(pl, &pl->stem_scale, pl->p, false));
+  TT_TRY(dev_alloc(pl, &pl->stem_shift, pl->p, false));
+  pl->x_rp.resize(pl->blocks.size());
+  pl->x_cp.resize(pl->blocks.size());
+  for (size_t i = 0; i < pl->blocks.size(); ++i) {
+    MultiHead &mh = pl->blocks[i];
+    TT_TRY(dev_alloc(pl, &pl->x_rp[i], (size_t)nb * mh.C * mh.H, true, ws));
+    TT_TRY(dev_alloc(pl, &pl->x_cp[i], (size_t)nb * mh.H * mh.W * (mh.C / 16), true, ws));
+    for (int b = 0; b < 4; ++b)   // zeroed once: the branch-padding border is never written again
+      TT_TRY(dev_alloc(pl, &mh.o[b], (size_t)nb * mh.Ho * mh.Wo * (mh.C / 16), true, ws));
+    for (BlockTT *b : {&mh.c1, &mh.c2, &mh.c3, &mh.cf}) {
+      const BlockGeom &g = b->g;
+      TT_TRY(dev_alloc(pl, (uint8_t **)&b->table, g.table_bytes(), true, tb));
+      TT_TRY(dev_alloc(pl, &b->perm_dev, b->perm.size(), false));
+      TT_HIP(hipMemcpy(b->perm_dev, b->perm.data(), b->perm.size(), hipMemcpyHostToDevice));
+      TT_TRY(dev_alloc(pl, &b->s1, (size_t)8 * g.in_planes, false));
+      TT_TRY(dev_alloc(pl, &b->t1, (size_t)8 * g.in_planes, false));
+      TT_TRY(dev_alloc(pl, &b->s2, g.out_planes, false));
+      TT_TRY(dev_alloc(pl, &b->t2, g.out_planes, false));
+      TT_TRY(dev_alloc(pl, &b->near_dev, 1, true));
+    }
+  }
+  TT_TRY(dev_alloc(pl, &pl->feat, (size_t)nb * pl->fcsize, true, ws));
+  TT_TRY(dev_alloc(pl, &pl->w1p, (size_t)pl->inter * pl->fcsize, false));
+  TT_TRY(dev_alloc(pl, &pl->bn_scale, pl->inter, false));
+  TT_TRY(dev_alloc(pl, &pl->bn_shift, pl->inter, false));
+  TT_TRY(dev_alloc(pl, &pl->mid, (size_t)nb * pl->inter, true, ws));
+  size_t pe = 0;
+  for (int n = 1; n <= nb; ++n) {
+    pe = std::max(pe, (size_t)gemm_splits(n, pl->inter, pl->fcsize) * n * pl->inter);
+    pe = std::max(pe, (size_t)gemm_splits(n, pl->n_classes, pl->inter) * n * pl->n_classes);
+  }
+  pl->part_elems = pe;
+  TT_TRY(dev_alloc(pl, &pl->part, pe, false, ws));
+  return TTNET_OK;
+}
+
+int fetch(const Tensor &t, std::vector<float> &host) {
+  host.resize(t.bytes / 4);
+  TT_HIP(hipMemcpy(host.data(), t.dev, t.bytes, hipMemcpyDeviceToHost));
+  return TTNET_OK;
+}
+
+// eval-mode BatchNorm as y = x*scale + shift, folded in float64
+int fold_bn(ttnet_plan *pl, const std::string &prefix, std::vector<double> &scale, std::vector<double> &shift) {
+  std::vector<float> w, b, m, v;
+  TT_TRY(fetch(pl->tensors[prefix + ".weight"], w));
+  TT_TRY(fetch(pl->tensors[prefix + ".bias"], b));
+  TT_TRY(fetch(pl->tensors[prefix + ".running_mean"], m));
+  TT_TRY(fetch(pl->tensors[prefix + ".running_var"], v));
+  scale.resize(w.size());
+  shift.resize(w.size());
+  for (size_t i = 0; i < w.size(); ++i) {
+    scale[i] = (double)w[i] / sqrt((double)v[i] + kBnEps);
+    shift[i] = (double)b[i] - (double)m[i] * scale[i];
+  }
+  return TTNET_OK;
+}
+
+int upload_f32(float *dst, const std::vector<double> &src) {
+  std::vector<float> f(src.begin(), src.end());
+  TT_HIP(hipMemcpy(dst, f.data(), f.size() * 4, hipMemcpyHostToDevice));
+  return TTNET_OK;
+}
+
+int build_table(ttnet_plan *pl, BlockTT &b, hipStream_t s) {
+  std::vector<double> s1, t1, s2, t2;
+  TT_TRY(fold_bn(pl, b.g.name + ".bn1", s1, t1));
+  TT_TRY(fold_bn(pl, b.g.name + ".bn2", s2, t2));
+  TT_HIP(hipMemcpy(b.s1, s1.data(), s1.size() * 8, hipMemcpyHostToDevice));
+  TT_HIP(hipMemcpy(b.t1, t1.data(), t1.size() * 8, hipMemcpyHostToDevice));
+  TT_HIP(hipMemcpy(b.s2, s2.data(), s2.size() * 8, hipMemcpyHostToDevice));
+  TT_HIP(hipMemcpy(b.t2, t2.data(), t2.size() * 8, hipMemcpyHostToDevice));
+  if (b.user_table) return TTNET_OK;
+  TT_HIP(hipMemsetAsync(b.near_dev, 0, sizeof(unsigned), s));
+  LutBuildArgs a{};
+  a.w1 = (const float *)pl->tensors[b.g.name + ".conv1.weight"].dev;
+  a.w2 = (const float *)pl->tensors[b.g.name + ".conv2.weight"].dev;
+  a.s1 = b.s1; a.t1 = b.t1; a.s2 = b.s2; a.t2 = b.t2;
+  a.perm = b.perm_dev;
+  a.groups = b.g.groups; a.n = b.g.nbits(); a.mid_g = b.g.mid_g(); a.cout_g = b.g.cout_g(); a.last = b.g.last;
+  a.table = b.table;
+  a.near_ties = b.near_dev;
+  return launch_lut_build(a, s);
+}
+
+void begin_timing(ttnet_plan *pl, const char *name, hipStream_t s) {
+  if (!pl->profiling) return;
+  if (pl->timing_used == pl->timings.size()) {
+    Timing t{name, nullptr, nullptr};
+    (void)hipEventCreate(&t.e0);
+    (void)hipEventCreate(&t.e1);
+    pl->timings.push_back(t);
+  }
+  pl->timings[pl->timing_used].name = name;
+  (void)hipEventRecord(pl->timings[pl->timing_used].e0, s);
+}
+void end_timing(ttnet_plan *pl, hipStream_t s) {
+  if (!pl->profiling) return;
+  (void)hipEventRecord(pl->timings[pl->timing_used].e1, s);
+  pl->timing_used++;
+}
+
+#define TT_TIMED(pl, name, s, expr) \
+  do {                              \
+    begin_timing(pl, name, s);      \
+    int r__ = (expr);               \
+    end_timing(pl, s);              \
+    if (r__ != TTNET_OK) return r__; \
+  } while (0)
+
+GateBlockArgs gate_args(ttnet_plan *pl, size_t i, int n) {
+  MultiHead &mh = pl->blocks[i];
+  GateBlockArgs a{};
+  a.n = n; a.C = mh.C; a.H = mh.H; a.W = mh.W; a.Ho = mh.Ho; a.Wo = mh.Wo; a.off34 = mh.off34;
+  a.kh1 = mh.c1.g.kh; a.kw1 = mh.c1.g.kw; a.kh2 = mh.c2.g.kh; a.kw2 = mh.c2.g.kw;
+  a.stride = mh.c1.g.stride; a.pad = mh.c1.g.pad;
+  a.x_rp = pl->x_rp[i]; a.x_cp = pl->x_cp[i];
+  a.t_dw1 = (const uint8_t *)mh.c1.table; a.t_dw2 = (const uint8_t *)mh.c2.table;
+  a.t_c3 = (const uint16_t *)mh.c3.table;
+  a.o1 = mh.o[0]; a.o2 = mh.o[1]; a.o3 = mh.o[2]; a.o4 = mh.o[3];
+  return a;
+}
+
+static const char *kDwNames[] = {"gate_dw.f4", "gate_dw.f5", "gate_dw.f6", "gate_dw.f7"};
+static const char *kPwNames[] = {"gate_pw.f4", "gate_pw.f5", "gate_pw.f6", "gate_pw.f7"};
+static const char *kPfNames[] = {"gate_pf.f4", "gate_pf.f5", "gate_pf.f6", "gate_pf.f7"};
+static const char *kTrNames[] = {"cp_to_rp.f4", "cp_to_rp.f5", "cp_to_rp.f6", "cp_to_rp.f7"};
+
+int run_from_blocks(ttnet_plan *pl, int n, float *logits, hipStream_t s) {
+  for (size_t i = 0; i < pl->blocks.size(); ++i) {
+    MultiHead &mh = pl->blocks[i];
+    GateBlockArgs a = gate_args(pl, i, n);
+    TT_TIMED(pl, kDwNames[i], s, launch_gate_dw(a, s));
+    TT_TIMED(pl, kPwNames[i], s, launch_gate_pw(a, s));
+    if (!mh.last) {
+      TT_TIMED(pl, kPfNames[i], s, launch_gate_pf(a, (const uint8_t *)mh.cf.table, pl->x_cp[i + 1], s));
+      TT_TIMED(pl, kTrNames[i], s,
+               launch_cp_to_rp(pl->x_cp[i + 1], pl->x_rp[i + 1], n, mh.cf.g.out_planes, mh.Ho, mh.Wo, s));
+    } else {
+      TT_TIMED(pl, "gate_last", s, launch_gate_last(a, (const float *)mh.cf.table, pl->feat, s));
+    }
+  }
+  const int s1 = gemm_splits(n, pl->inter, pl->fcsize);
+  TT_TIMED(pl, "head.lin1", s, launch_gemm_nt_splitk(pl->feat, pl->w1p, pl->part, n, pl->inter, pl->fcsize, s1, s));
+  TT_TIMED(pl, "head.bn_poly", s, launch_head_mid(pl->part, s1, pl->bn_scale, pl->bn_shift, pl->mid, n, pl->inter, s));
+  const int s2 = gemm_splits(n, pl->n_classes, pl->inter);
+  TT_TIMED(pl, "head.lin2", s,
+           launch_gemm_nt_splitk(pl->mid, (const float *)pl->tensors[pl->head + ".lin2.weight"].dev, pl->part, n,
+                                 pl->n_classes, pl->inter, s2, s));
+  TT_TIMED(pl, "head.bias", s,
+           launch_head_out(pl->part, s2, (const float *)pl->tensors[pl->head + ".lin2.bias"].dev, logits, n,
+                           pl->n_classes, s));
+  pl->last_n = n;
+  return TTNET_OK;
+}
+
+int check_ready(ttnet_plan *pl, const void *in, int64_t n, const void *out) {
+  if (!pl || !in || !out) {
+    set_error("null argument");
+    return TTNET_E_INVALID;
+  }
+  if (!pl->finalized) {
+    set_error("ttnet_forward before ttnet_plan_finalize");
+    return TTNET_E_STATE;
+  }
+  if (n < 1 || n > pl->desc.max_batch) {
+    set_error("batch %lld outside [1, max_batch=%d]", (long long)n, pl->desc.max_batch);
+    return TTNET_E_INVALID;
+  }
+  return TTNET_OK;
+}
+
+BlockTT *find_block(ttnet_plan *pl, const char *name) {
+  for (auto &mh : pl->blocks)
+    for (BlockTT *b : {&mh.c1, &mh.c2, &mh.c3, &mh.cf})
+      if (b->g.name == name) return b;
+  return nullptr;
+}
+
+// canonical index (pattern read MSB first over (c,kh,kw), TT_FHE_SMALL.py:330-334) of an
+// internal index
+inline uint32_t canonical_index(const BlockTT &b, uint32_t idx) {
+  const int n = b.g.nbits();
+  uint32_t ci = 0;
+  for (int p = 0; p < n; ++p)
+    if ((idx >> p) & 1u) ci |= 1u << (n - 1 - b.perm[p]);
+  return ci;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *ttnet_last_error(void) { return g_err; }
+const char *ttnet_version(void) { return "ttnet-mi355x 0.1 (gfx950)"; }
+
+int ttnet_plan_create(const ttnet_net_desc *desc, int device, ttnet_plan **out) {
+  if (!desc || !out) {
+    set_error("null argument");
+    return TTNET_E_INVALID;
+  }
+  *out = nullptr;
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count < 1) {
+    set_error("no HIP device: libttnet has no CPU path");
+    return TTNET_E_HIP;
+  }
+  if (device < 0 || device >= count) {
+    set_error("device %d out of range (%d devices)", device, count);
+    return TTNET_E_INVALID;
+  }
+  TT_HIP(hipSetDevice(device));
+  std::unique_ptr<ttnet_plan> pl(new ttnet_plan());
+  pl->desc = *desc;
+  pl->device = device;
+  int st = build_geometry(pl.get());
+  if (st == TTNET_OK) st = allocate(pl.get());
+  if (st != TTNET_OK) {
+    for (void *ptr : pl->owned) (void)hipFree(ptr);
+    return st;
+  }
+  *out = pl.release();
+  return TTNET_OK;
+}
+
+int ttnet_plan_set_tensor(ttnet_plan *pl, const char *key, const void *ptr, const int64_t *shape, int ndim,
+                          int dtype, int on_device) {
+  if (!pl || !key || !ptr || (ndim > 0 && !shape)) {
+    set_error("null argument");
+    return TTNET_E_INVALID;
+  }
+  std::string k(key);
+  if (k.rfind("module.", 0) == 0) k = k.substr(7);   // DataParallel / DDP checkpoints (main.py:181-192)
+  auto it = pl->tensors.find(k);
+  if (it == pl->tensors.end()) {
+    set_error("unexpected key in state_dict: %s", key);
+    return TTNET_E_INVALID;
+  }
+  Tensor &t = it->second;
+  bool ok = (dtype == t.dtype) && (ndim == (int)t.shape.size());
+  for (int i = 0; ok && i < ndim; ++i) ok = shape[i] == t.shape[i];
+  if (!ok) {
+    set_error("size mismatch for %s", key);
+    return TTNET_E_INVALID;
+  }
+  TT_HIP(hipSetDevice(pl->device));
+  TT_HIP(hipMemcpy(t.dev, ptr, t.bytes, on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
+  t.set = true;
+  pl->finalized = false;
+  return TTNET_OK;
+}
+
+int ttnet_plan_finalize(ttnet_plan *pl, void *stream) {
+  if (!pl) {
+    set_error("null plan");
+    return TTNET_E_INVALID;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  TT_HIP(hipSetDevice(pl->device));
+  for (auto &k : pl->key_order) {
+    const Tensor &t = pl->tensors[k];
+    if (t.required && !t.set) {
+      set_error("missing key in state_dict: %s", k.c_str());
+      return TTNET_E_STATE;
+    }
+  }
+  // stem: weights to tap-major [147][p]; BN folded to fp32 scale/shift
+  {
+    std::vector<float> w;
+    TT_TRY(fetch(pl->tensors["features.1.weight"], w));
+    std::vector<float> wt((size_t)147 * pl->p);
+    for (int ch = 0; ch < pl->p; ++ch)
+      for (int tap = 0; tap < 147; ++tap) wt[(size_t)tap * pl->p + ch] = w[(size_t)ch * 147 + tap];
+    TT_HIP(hipMemcpy(pl->stem_wt, wt.data(), wt.size() * 4, hipMemcpyHostToDevice));
+    std::vector<double> sc, sh;
+    TT_TRY(fold_bn(pl, "features.2", sc, sh));
+    TT_TRY(upload_f32(pl->stem_scale, sc));
+    TT_TRY(upload_f32(pl->stem_shift, sh));
+  }
+  for (auto &mh : pl->blocks)
+    for (BlockTT *b : {&mh.c1, &mh.c2, &mh.c3, &mh.cf}) TT_TRY(build_table(pl, *b, s));
+  {
+    std::vector<double> sc, sh;
+    TT_TRY(fold_bn(pl, pl->head + ".BN2", sc, sh));
+    TT_TRY(upload_f32(pl->bn_scale, sc));
+    TT_TRY(upload_f32(pl->bn_shift, sh));
+    TT_TRY(launch_permute_lin1((const float *)pl->tensors[pl->head + ".lin1.weight"].dev, pl->w1p, pl->inter,
+                               pl->featC / 16, pl->featPP, s));
+  }
+  TT_HIP(hipStreamSynchronize(s));
+  for (auto &mh : pl->blocks)
+    for (BlockTT *b : {&mh.c1, &mh.c2, &mh.c3, &mh.cf}) {
+      if (b->user_table) continue;
+      unsigned v = 0;
+      TT_HIP(hipMemcpy(&v, b->near_dev, sizeof(v), hipMemcpyDeviceToHost));
+      b->near_ties = v;
+    }
+  pl->finalized = true;
+  return TTNET_OK;
+}
+
+int ttnet_forward(ttnet_plan *pl, const float *x_dev, int64_t n, float *logits_dev, void *stream) {
+  TT_TRY(check_ready(pl, x_dev, n, logits_dev));
+  hipStream_t s = (hipStream_t)stream;
+  pl->timing_used = 0;
+  TT_TIMED(pl, "stem", s,
+           launch_stem(x_dev, pl->stem_wt, pl->stem_scale, pl->stem_shift, pl->x_rp[0], pl->x_cp[0], (int)n, pl->p, s));
+  return run_from_blocks(pl, (int)n, logits_dev, s);
+}
+
+int ttnet_forward_from_stem_bits(ttnet_plan *pl, const uint64_t *rows_dev, int64_t n, float *logits_dev,
+                                 void *stream) {
+  TT_TRY(check_ready(pl, rows_dev, n, logits_dev));
+  hipStream_t s = (hipStream_t)stream;
+  pl->timing_used = 0;
+  const MultiHead &b0 = pl->blocks[0];
+  TT_HIP(hipMemcpyAsync(pl->x_rp[0], rows_dev, (size_t)n * b0.C * b0.H * 8, hipMemcpyDeviceToDevice, s));
+  TT_TRY(launch_rp_to_cp(pl->x_rp[0], pl->x_cp[0], (int)n, b0.C, b0.H, b0.W, s));
+  return run_from_blocks(pl, (int)n, logits_dev, s);
+}
+
+int ttnet_read_stage(ttnet_plan *pl, const char *stage, int64_t n, void *dst, size_t dst_bytes, int on_device,
+                     void *stream) {
+  if (!pl || !stage || !dst) {
+    set_error("null argument");
+    return TTNET_E_INVALID;
+  }
+  if (n < 1 || n > pl->last_n) {
+    set_error("read_stage: n=%lld but the last forward ran %lld images", (long long)n, (long long)pl->last_n);
+    return TTNET_E_STATE;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  const std::string st(stage);
+  const hipMemcpyKind kind = on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
+  auto copy_out = [&](const void *src, size_t bytes) -> int {
+    if (dst_bytes != bytes) {
+      set_error("read_stage(%s): destination is %zu bytes, stage is %zu", stage, dst_bytes, bytes);
+      return TTNET_E_INVALID;
+    }
+    TT_HIP(hipMemcpyAsync(dst, src, bytes, kind, s));
+    TT_HIP(hipStreamSynchronize(s));
+    return TTNET_OK;
+  };
+  for (size_t i = 0; i < pl->blocks.size(); ++i) {
+    MultiHead &mh = pl->blocks[i];
+    const std::string in_name = i == 0 ? std::string("features.3") : pl->blocks[i - 1].name;
+    if (st == in_name) return copy_out(pl->x_rp[i], (size_t)n * mh.C * mh.H * 8);
+    for (int b = 0; b < 4; ++b) {
+      if (st == mh.name + ".out" + std::to_string(b + 1)) {
+        uint64_t *tmp = nullptr;
+        const size_t words = (size_t)n * mh.C * mh.Ho;
+        TT_HIP(hipMalloc((void **)&tmp, words * 8));
+        int r = launch_cp_to_rp(mh.o[b], tmp, (int)n, mh.C, mh.Ho, mh.Wo, s);
+        if (r == TTNET_OK) r = copy_out(tmp, words * 8);
+        (void)hipFree(tmp);
+        return r;
+      }
+    }
+  }
+  if (st == "flatten") {
+    float *tmp = nullptr;
+    const size_t elems = (size_t)n * pl->fcsize;
+    TT_HIP(hipMalloc((void **)&tmp, elems * 4));
+    int r = launch_feat_to_reference_order(pl->feat, tmp, (int)n, pl->featC / 16, pl->featPP, s);
+    if (r == TTNET_OK) r = copy_out(tmp, elems * 4);
+    (void)hipFree(tmp);
+    return r;
+  }
+  set_error("unknown stage %s", stage);
+  return TTNET_E_INVALID;
+}
+
+int ttnet_plan_get_table(ttnet_plan *pl, const char *name, void *dst_host, size_t dst_bytes) {
+  if (!pl || !name || !dst_host) {
+    set_error("null argument");
+    return TTNET_E_INVALID;
+  }
+  BlockTT *b = find_block(pl, name);
+  if (!b) {
+    set_error("no Block_TT named %s", name);
+    return TTNET_E_INVALID;
+  }
+  if (!pl->finalized) {
+    set_error("get_table before finalize");
+    return TTNET_E_STATE;
+  }
+  const BlockGeom &g = b->g;
+  const size_t entries = (size_t)1 << g.nbits();
+  const size_t need = (size_t)g.groups * entries * g.cout_g() * (g.last ? 4 : 1);
+  if (dst_bytes != need) {
+    set_error("get_table(%s): destination is %zu bytes, table is %zu", name, dst_bytes, need);
+    return TTNET_E_INVALID;
+  }
+  std::vector<uint8_t> raw(g.table_bytes());
+  TT_HIP(hipMemcpy(raw.data(), b->table, raw.size(), hipMemcpyDeviceToHost));
+  const int cg = g.cout_g(), eb = g.entry_bits();
+  const size_t group_bytes_1 = entries >= 32 ? entries / 8 : 4;
+  for (int grp = 0; grp < g.groups; ++grp)
+    for (uint32_t idx = 0; idx < entries; ++idx) {
+      const size_t ci = canonical_index(*b, idx);
+      if (g.last) {
+        memcpy((float *)dst_host + ((size_t)grp * entries + ci) * cg,
+               (const float *)raw.data() + ((size_t)grp * entries + idx) * cg, (size_t)cg * 4);
+        continue;
+      }
+      uint32_t bits;
+      if (eb == 1) bits = (raw[grp * group_bytes_1 + (idx >> 3)] >> (idx & 7)) & 1u;
+      else if (eb == 8) bits = raw[(size_t)grp * entries + idx];
+      else bits = ((const uint16_t *)raw.data())[(size_t)grp * entries + idx];
+      uint8_t *d = (uint8_t *)dst_host + ((size_t)grp * entries + ci) * cg;
+      for (int o = 0; o < cg; ++o) d[o] = (bits >> o) & 1u;
+    }
+  return TTNET_OK;
+}
+
+int ttnet_plan_set_table(ttnet_plan *pl, const char *name, const void *src_host, size_t src_bytes) {
+  if (!pl || !name || !src_host) {
+    set_error("null argument");
+    return TTNET_E_INVALID;
+  }
+  BlockTT *b = find_block(pl, name);
+  if (!b) {
+    set_error("no Block_TT named %s", name);
+    return TTNET_E_INVALID;
+  }
+  const BlockGeom &g = b->g;
+  const size_t entries = (size_t)1 << g.nbits();
+  const size_t need = (size_t)g.groups * entries * g.cout_g() * (g.last ? 4 : 1);
+  if (src_bytes != need) {
+    set_error("set_table(%s): source is %zu bytes, table is %zu", name, src_bytes, need);
+    return TTNET_E_INVALID;
+  }
+  std::vector<uint8_t> raw(g.table_bytes(), 0);
+  const int cg = g.cout_g(), eb = g.entry_bits();
+  const size_t group_bytes_1 = entries >= 32 ? entries / 8 : 4;
+  for (int grp = 0; grp < g.groups; ++grp)
+    for (uint32_t idx = 0; idx < entries; ++idx) {
+      const size_t ci = canonical_index(*b, idx);
+      if (g.last) {
+        memcpy((float *)raw.data() + ((size_t)grp * entries + idx) * cg,
+               (const float *)src_host + ((size_t)grp * entries + ci) * cg, (size_t)cg * 4);
+        continue;
+      }
+      const uint8_t *sp = (const uint8_t *)src_host + ((size_t)grp * entries + ci) * cg;
+      uint32_t bits = 0;
+      for (int o = 0; o < cg; ++o) bits |= (uint32_t)(sp[o] & 1u) << o;
+      if (eb == 1) raw[grp * group_bytes_1 + (idx >> 3)] |= (uint8_t)(bits << (idx & 7));
+      else if (eb == 8) raw[(size_t)grp * entries + idx] = (uint8_t)bits;
+      else ((uint16_t *)raw.data())[(size_t)grp * entries + idx] = (uint16_t)bits;
+    }
+  TT_HIP(hipSetDevice(pl->device));
+  TT_HIP(hipMemcpy(b->table, raw.data(), raw.size(), hipMemcpyHostToDevice));
+  b->user_table = true;
+  b->near_ties = -1;
+  return TTNET_OK;
+}
+
+int ttnet_plan_query(ttnet_plan *pl, const char *what, int64_t *out) {
+  if (!pl || !what || !out) {
+    set_error("null argument");
+    return TTNET_E_INVALID;
+  }
+  const std::string w(what);
+  if (w == "fcsize") *out = pl->fcsize;
+  else if (w == "n_classes") *out = pl->n_classes;
+  else if (w == "n_state_tensors") *out = (int64_t)pl->key_order.size();
+  else if (w == "max_batch") *out = pl->desc.max_batch;
+  else if (w == "table_bytes") *out = (int64_t)pl->table_bytes;
+  else if (w == "workspace_bytes") *out = (int64_t)pl->workspace_bytes;
+  else if (w == "p") *out = pl->p;
+  else if (w.rfind("near_ties:", 0) == 0) {
+    BlockTT *b = find_block(pl, w.c_str() + 10);
+    if (!b) {
+      set_error("no Block_TT named %s", w.c_str() + 10);
+      return TTNET_E_INVALID;
+    }
+    *out = b->near_ties;
+  } else {
+    set_error("unknown query %s", what);
+    return TTNET_E_INVALID;
+  }
+  return TTNET_OK;
+}
+
+int ttnet_plan_set_profiling(ttnet_plan *pl, int enabled) {
+  if (!pl) {
+    set_error("null plan");
+    return TTNET_E_INVALID;
+  }
+  pl->profiling = enabled != 0;
+  pl->timing_used = 0;
+  return TTNET_OK;
+}
+
+int ttnet_plan_last_timings(ttnet_plan *pl, const char **names, float *ms, int cap) {
+  if (!pl || !names || !ms) {
+    set_error("null argument");
+    return TTNET_E_INVALID;
+  }
+  int k = 0;
+  for (size_t i = 0; i < pl->timing_used && k < cap; ++i, ++k) {
+    if (hipEventSynchronize(pl->timings[i].e1) != hipSuccess) {
+      set_error("hipEventSynchronize failed");
+      return TTNET_E_HIP;
+    }
+    float t = 0.f;
+    (void)hipEventElapsedTime(&t, pl->timings[i].e0, pl->timings[i].e1);
+    names[k] = pl->timings[i].name;
+    ms[k] = t;
+  }
+  return k;
+}
+
+void ttnet_plan_destroy(ttnet_plan *pl) {
+  if (!pl) return;
+  (void)hipSetDevice(pl->device);
+  for (auto &t : pl->timings) {
+    (void)hipEventDestroy(t.e0);
+    (void)hipEventDestroy(t.e1);
+  }
+  for (void *ptr : pl->owned) (void)hipFree(ptr);
+  delete pl;
+}
+
+// ---- logits all-gather over RCCL (xGMI) ------------------------------------------------------
+// librccl is resolved at first use so that a process which already carries an RCCL (e.g.
+// the one inside PyTorch-ROCm) keeps exactly one copy.
+
+struct ttnet_comm {
+  void *nccl = nullptr;
+  int rank = 0, world = 1, device = 0;
+};
+
+namespace {
+struct Id128 {
+  char b[128];   // ncclUniqueId, passed by value
+};
+struct Rccl {
+  void *lib = nullptr;
+  int (*GetUniqueId)(void *) = nullptr;
+  int (*CommInitRank)(void **, int, Id128, int) = nullptr;
+  int (*AllGather)(const void *, void *, size_t, int, void *, hipStream_t) = nullptr;
+  int (*CommDestroy)(void *) = nullptr;
+  const char *(*GetErrorString)(int) = nullptr;
+};
+Rccl g_rccl;
+
+int load_rccl() {
+  if (g_rccl.lib) return TTNET_OK;
+  const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};
+  void *h = nullptr;
+  for (const char *nm : names) {
+    h = dlopen(nm, RTLD_NOW | RTLD_GLOBAL);
+    if (h) break;
+  }
+  if (!h) {
+    set_error("cannot load librccl: %s", dlerror());
+    return TTNET_E_UNSUPPORTED;
+  }
+  g_rccl.GetUniqueId = (decltype(g_rccl.GetUniqueId))dlsym(h, "ncclGetUniqueId");
+  g_rccl.CommInitRank = (decltype(g_rccl.CommInitRank))dlsym(h, "ncclCommInitRank");
+  g_rccl.AllGather = (decltype(g_rccl.AllGather))dlsym(h, "ncclAllGather");
+  g_rccl.CommDestroy = (decltype(g_rccl.CommDestroy))dlsym(h, "ncclCommDestroy");
+  g_rccl.GetErrorString = (decltype(g_rccl.GetErrorString))dlsym(h, "ncclGetErrorString");
+  if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.AllGather || !g_rccl.CommDestroy) {
+    set_error("librccl lacks an expected symbol");
+    return TTNET_E_UNSUPPORTED;
+  }
+  g_rccl.lib = h;
+  return TTNET_OK;
+}
+
+int rccl_check(int r, const char *what) {
+  if (r == 0) return TTNET_OK;
+  set_error("%s failed: %s", what, g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "rccl error");
+  return TTNET_E_HIP;
+}
+}  // namespace
+
+int ttnet_comm_unique_id(void *id128) {
+  if (!id128) {
+    set_error("null argument");
+    return TTNET_E_INVALID;
+  }
+  TT_TRY(load_rccl());
+  return rccl_check(g_rccl.GetUniqueId(id128), "ncclGetUniqueId");
+}
+
+int ttnet_comm_create(const void *id128, int rank, int world, int device, ttnet_comm **out) {
+  if (!id128 || !out || world < 1 || rank < 0 || rank >= world) {
+    set_error("bad argument to ttnet_comm_create");
+    return TTNET_E_INVALID;
+  }
+  TT_TRY(load_rccl());
+  TT_HIP(hipSetDevice(device));
+  std::unique_ptr<ttnet_comm> c(new ttnet_comm());
+  c->rank = rank; c->world = world; c->device = device;
+  Id128 id;
+  memcpy(id.b, id128, 128);
+  TT_TRY(rccl_check(g_rccl.CommInitRank(&c->nccl, world, id, rank), "ncclCommInitRank"));
+  *out = c.release();
+  return TTNET_OK;
+}
+
+int ttnet_allgather_logits(ttnet_comm *comm, const float *local_dev, int64_t n_local, int64_t n_classes,
+                           float *all_dev, void *stream) {
+  if (!comm || !local_dev || !all_dev || n_local < 1 || n_classes < 1) {
+    set_error("bad argument to ttnet_allgather_logits");
+    return TTNET_E_INVALID;
+  }
+  // ncclFloat32 == 7
+  return rccl_check(g_rccl.AllGather(local_dev, all_dev, (size_t)(n_local * n_classes), 7, comm->nccl,
+                                     (hipStream_t)stream),
+                    "ncclAllGather");
+}
+
+void ttnet_comm_destroy(ttnet_comm *comm) {
+  if (!comm) return;
+  if (comm->nccl && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(comm->nccl);
+  delete comm;
+}
+
+}  // extern "C"

@@ -1,0 +1,109 @@
+// Internal declarations shared by the HIP translation units of libttnet.so.
+// gfx950 (MI355X) only: 64-wide wavefronts, 160 KiB LDS per CU.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+
+#include "../../include/ttnet.h"
+
+namespace ttnet {
+
+void set_error(const char *fmt, ...);
+
+#define TT_HIP(call)                                                                       \
+  do {                                                                                     \
+    hipError_t e__ = (call);                                                               \
+    if (e__ != hipSuccess) {                                                               \
+      ::ttnet::set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e__), __FILE__, \
+                         __LINE__);                                                        \
+      return TTNET_E_HIP;                                                                  \
+    }                                                                                      \
+  } while (0)
+
+#define TT_TRY(expr)          \
+  do {                        \
+    int s__ = (expr);         \
+    if (s__ != TTNET_OK) return s__; \
+  } while (0)
+
+constexpr int kWave = 64;
+constexpr int kMaxLds = 160 * 1024;
+
+// Geometry of one Block_TT (models/TT_FHE_SMALL.py:281-305).
+struct BlockGeom {
+  std::string name;
+  int in_planes = 0, out_planes = 0, kh = 1, kw = 1, stride = 1, pad = 0, groups = 1;
+  bool last = false;
+  int cin_g() const { return in_planes / groups; }
+  int mid_g() const { return 8 * in_planes / groups; }
+  int cout_g() const { return out_planes / groups; }
+  int nbits() const { return cin_g() * kh * kw; }
+  // internal table entry width in bits: 1 (bit-packed along the index), 8 or 16
+  int entry_bits() const { return last ? 32 * cout_g() : (cout_g() == 1 ? 1 : (cout_g() <= 8 ? 8 : 16)); }
+  size_t table_bytes() const {
+    size_t entries = (size_t)groups << nbits();
+    if (last) return entries * cout_g() * sizeof(float);
+    size_t b = entries * entry_bits() / 8;
+    return b < 4 ? 4 : b;
+  }
+};
+
+// ---- launchers (defined next to their kernels) ------------------------------------------
+
+// lut_build.hip
+struct LutBuildArgs {
+  const float *w1;      // conv1.weight [G*mid_g][n] (canonical column order c,kh,kw)
+  const float *w2;      // conv2.weight [G*cout_g][mid_g]
+  const double *s1, *t1;  // folded bn1 [G*mid_g]
+  const double *s2, *t2;  // folded bn2 [G*cout_g]
+  const uint8_t *perm;  // [n] internal index bit p -> canonical input column
+  int groups, n, mid_g, cout_g, last;
+  void *table;          // internal layout (see BlockGeom::entry_bits)
+  unsigned *near_ties;  // one counter
+};
+int launch_lut_build(const LutBuildArgs &a, hipStream_t s);
+
+// stem.hip
+int launch_stem(const float *x, const float *wt, const float *scale, const float *shift, uint64_t *rp,
+                uint16_t *cp, int n, int p, hipStream_t s);
+
+// gate.hip
+struct GateBlockArgs {
+  int n;                 // images
+  int C, H, W;           // input planes and size
+  int Ho, Wo;            // branch output size after padding
+  int off34;             // left/top zero padding of out3/out4 (1 at W=56, else 0)
+  int kh1, kw1, kh2, kw2, stride, pad;
+  const uint64_t *x_rp;  // [n][C][H]
+  const uint16_t *x_cp;  // [n][H][W][C/16]
+  const uint8_t *t_dw1, *t_dw2;   // [C][2^n/8]
+  const uint16_t *t_c3;           // [C/16][65536]
+  uint16_t *o1, *o2, *o3, *o4;    // [n][Ho][Wo][C/16]
+};
+int launch_gate_dw(const GateBlockArgs &a, hipStream_t s);
+int launch_gate_pw(const GateBlockArgs &a, hipStream_t s);
+// convf of a non-last block: 4 branch tensors -> CP [n][Ho][Wo][Cout/16], Cout = 8 * (4C/16)
+int launch_gate_pf(const GateBlockArgs &a, const uint8_t *t_cf, uint16_t *out_cp, hipStream_t s);
+// convf of the last block through the float table: -> feat [n][4C/16][pooled][16]
+int launch_gate_last(const GateBlockArgs &a, const float *t_last, float *feat, hipStream_t s);
+int launch_cp_to_rp(const uint16_t *cp, uint64_t *rp, int n, int C, int H, int W, hipStream_t s);
+int launch_rp_to_cp(const uint64_t *rp, uint16_t *cp, int n, int C, int H, int W, hipStream_t s);
+// feat [n][G][PP][16] (device order) -> [n][(16g+k)*PP + pp] (reference Flatten order)
+int launch_feat_to_reference_order(const float *feat, float *out, int n, int G, int PP, hipStream_t s);
+
+// head.hip
+// C[M][N] (+)= A[M][K] * B[N][K]^T as split-K slabs: part[S][M][N]
+int launch_gemm_nt_splitk(const float *A, const float *B, float *part, int M, int N, int K, int splits,
+                          hipStream_t s);
+// z = sum_s part; z = z*scale+shift; out = 0.47+0.5z+0.09z^2   (Classifier_scale middle)
+int launch_head_mid(const float *part, int splits, const float *scale, const float *shift, float *out, int M,
+                    int N, hipStream_t s);
+// out = sum_s part + bias
+int launch_head_out(const float *part, int splits, const float *bias, float *out, int M, int N, hipStream_t s);
+// W1p[o][(g*PP+pp)*16+k] = W1[o][(16g+k)*PP+pp]
+int launch_permute_lin1(const float *w1, float *w1p, int O, int G, int PP, hipStream_t s);
+
+}  // namespace ttnet
