@@ -1,0 +1,219 @@
+#!/usr/bin/env python3
+"""Benchmark of the hot path: images/s of the TT-small forward on MI355X.
+
+    python bench.py [--gpus N --steps K --warmup W] [--batch B]
+
+A step is one forward of ``--batch`` (default 256, BASELINE.json configs[1]) synthetic
+224x224 images per GPU, already resident in HBM, plus -- for N > 1 -- the all-gather of the
+logits (RCCL).  One process per GPU (torchrun env), batch sharded by image, weak scaling
+(per-GPU batch fixed).  Rank 0 prints ONE JSON line with the driver's contract fields plus
+
+  roofline          the dominant kernel by device time: algorithmic flops (or bytes) per
+                    launch / its average launch duration, measured with HIP events on the
+                    launch stream in a second pass of K steps (the event pairs would
+                    perturb the throughput pass); peaks from MI355X_MICROARCH.md
+  roofline_kernels  the same for every kernel, and for the gate (LUT) path as a whole
+                    against HBM with SURVEY 8(d)'s algorithmic bytes 74,592*B + 14,155,776
+  cpu_baseline      the oracle's float-mode restatement of the reference forward
+                    (oracle/ttnet_float.py, torch-CPU, all host threads) timed on a bounded
+                    sample on rank 0 at N = 1 -- a reported baseline, not the target.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from argparse import Namespace
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from scale_imagenet_amd import synth, ttnet
+from scale_imagenet_amd.dist import all_gather_logits, init_from_env
+from scale_imagenet_amd.spec import make_spec
+
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s achievable)
+F32_PEAK_TFLOPS = 157.3      # fp32 matrix == fp32 vector peak; exact-f32 MFMA
+
+# algorithmic work per image; MACs -> 2 flops
+STEM_MAC, LIN1_MAC, LIN2_MAC = 29_503_488, 16_384_000, 1_000_000
+GATE_BYTES_PER_IMAGE, GATE_TABLE_BYTES = 74_592, 14_155_776
+
+
+def kernel_models(batch: int):
+    """name -> (bound, algorithmic units per launch).  Gate kernels: packed input + output
+    bytes of that launch + its tables once (the unfused per-layer accounting of SURVEY 8(d))."""
+    m = {
+        "stem": ("mfma", 2.0 * STEM_MAC * batch),
+        "head.lin1": ("mfma", 2.0 * LIN1_MAC * batch),
+        "head.lin2": ("mfma", 2.0 * LIN2_MAC * batch),
+        "head.bn_poly": ("hbm", 8.0 * 1000 * batch),
+        "head.bias": ("hbm", 8.0 * 1000 * batch),
+    }
+    c, h = 64, 56
+    for i, tag in enumerate(("f4", "f5", "f6")):
+        ho = h // 2 + 1
+        plane_in, plane_out = c * h * h / 8.0, c * ho * ho / 8.0
+        m[f"gate_dw.{tag}"] = ("hbm", batch * (plane_in + 2 * plane_out) + 2 * c * 8192)
+        m[f"gate_pw.{tag}"] = ("hbm", batch * (plane_in + 2 * plane_out) + (c // 16) * 131072)
+        if i < 2:
+            m[f"gate_pf.{tag}"] = ("hbm", batch * (4 * plane_out + 2 * plane_out) + (c // 4) * 65536)
+            m[f"cp_to_rp.{tag}"] = ("hbm", batch * (4 * plane_out))
+        else:
+            # 4 branch tensors in, one 64-byte table row per (group, pixel), pooled floats out
+            m["gate_last"] = ("hbm", batch * (4 * plane_out + (c // 4) * ho * ho * 64 + 4 * c * 16 * 4))
+        c, h = 2 * c, ho
+    return m
+
+
+def host_cores() -> int:
+    """CPU threads this process may really use: affinity mask capped by the cgroup quota
+    (the GPU box exposes 256 logical CPUs but grants a 1-GPU job a 16-CPU share)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(n, int(os.environ.get("TTNET_CPU_THREADS", "16"))))
+
+
+def cpu_baseline(spec, st, budget_s: float = 15.0):
+    """The oracle's float-mode forward (the reference's op sequence, incl. its inert
+    randint_like and clones) on all host threads, bounded sample."""
+    from oracle import ttnet_float as OF
+    cores = host_cores()
+    torch.set_num_threads(cores)
+    sd = OF.to_torch_state(st)
+    bs = 32
+    x = torch.from_numpy(synth.synth_images(bs))
+    OF.forward(x, sd, spec)                       # warm-up
+    t0 = time.perf_counter()
+    done = 0
+    while True:
+        OF.forward(x, sd, spec)
+        done += bs
+        el = time.perf_counter() - t0
+        if el >= budget_s or done >= 16 * bs:
+            break
+    return {"value": done / el, "unit": "images/s", "cores": cores, "kind": "port",
+            "sample": f"{done} images as batches of {bs} (same synthetic generator and weights), "
+                      f"oracle/ttnet_float.py = the reference's eval op sequence on torch-CPU "
+                      f"{torch.__version__}, {cores} threads, {el:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=256, help="images per GPU per step")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank, world, local_rank = init_from_env("nccl")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    assert torch.cuda.is_available(), "bench.py needs a HIP device (the product has no CPU path)"
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    spec = make_spec("small")
+    st = synth.synth_state_dict(spec)
+    model = ttnet.TT_vf_19lv3_imgnet_small(Namespace(nfilter=8, tfilter=8, layers=1, groups=[1, None, 4, None]))
+    model.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in st.items()}, strict=True)
+    model = model.to(dev).eval().reserve(args.batch)
+
+    B = args.batch
+    n_total = B * world
+    x = torch.from_numpy(synth.synth_images(B, first=rank * B)).to(dev)      # resident in HBM
+
+    def step():
+        with torch.no_grad():
+            y = model(x)
+            return all_gather_logits(y, n_total) if world > 1 else y
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        y = step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # second pass: per-kernel device time with HIP events on the launch stream
+    model.set_profiling(True)
+    acc = {}
+    for _ in range(args.steps):
+        step()
+        for k, v in model.last_timings().items():
+            acc[k] = acc.get(k, 0.0) + v
+    model.set_profiling(False)
+    avg_ms = {k: v / args.steps for k, v in acc.items()}
+
+    if rank == 0:
+        models = kernel_models(B)
+        kernels = []
+        for k, ms in avg_ms.items():
+            bound, units = models.get(k, ("hbm", 0.0))
+            if bound == "mfma":
+                ach, peak, unit = units / (ms * 1e-3) / 1e12, F32_PEAK_TFLOPS, "TFLOP/s"
+            else:
+                ach, peak, unit = units / (ms * 1e-3) / 1e9, HBM_PEAK_GBS, "GB/s"
+            kernels.append({"kernel": k, "ms": round(ms, 5), "bound": bound, "achieved": round(ach, 3),
+                            "peak": peak, "unit": unit, "frac": round(ach / peak, 5), "traffic": None})
+        gate_ms = sum(ms for k, ms in avg_ms.items() if k.startswith(("gate_dw", "gate_pw", "gate_pf", "cp_to_rp")))
+        gate_bytes = GATE_BYTES_PER_IMAGE * B + GATE_TABLE_BYTES
+        gate = {"kernel": "gate_path (all binarised LUT launches)", "ms": round(gate_ms, 5), "bound": "hbm",
+                "achieved": round(gate_bytes / (gate_ms * 1e-3) / 1e9, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(gate_bytes / (gate_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "traffic": None}
+        dom = max(kernels, key=lambda r: r["ms"])
+        roofline = {k: dom[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic")}
+        roofline["kernel"] = dom["kernel"]
+        roofline["ms"] = dom["ms"]
+        out = {
+            "metric": "images/sec ImageNet 224x224, TT-small, MI355X; top-1 exact-match",
+            "value": round(n_total * args.steps / elapsed, 2),
+            "unit": "images/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * elapsed / args.steps, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u16/u64 packed bits + f32",
+            "data": "synthetic",
+            "config": {"workload": f"TT_general_imagenet_v2_small forward, batch={B} 224x224 per GPU, "
+                                   f"bit-packed HIP LUT kernels (BASELINE.json configs[1])",
+                       "batch_per_gpu": B, "global_batch": n_total,
+                       "parallelism": f"batch shard x{world}" + (" + RCCL all-gather of logits" if world > 1 else "")},
+            "roofline": roofline,
+            "roofline_kernels": kernels + [gate],
+            "kernel_ms_sum": round(sum(avg_ms.values()), 5),
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(spec, st)
+            out["gpu_over_cpu"] = round(out["value"] / out["cpu_baseline"]["value"], 1)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -536,6 +536,10 @@ int ttnet_plan_set_tensor(ttnet_plan *pl, const char *key, const void *ptr, cons
   TT_HIP(hipMemcpy(t.dev, ptr, t.bytes, on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
   t.set = true;
   pl->finalized = false;
+  // new parameters for a Block_TT invalidate a table injected with ttnet_plan_set_table
+  for (auto &mh : pl->blocks)
+    for (BlockTT *b : {&mh.c1, &mh.c2, &mh.c3, &mh.cf})
+      if (k.compare(0, b->g.name.size() + 1, b->g.name + ".") == 0) b->user_table = false;
   return TTNET_OK;
 }
 

@@ -1,0 +1,51 @@
+"""Shared helpers for the tests (test infrastructure; may import oracle/)."""
+import hashlib
+import json
+import os
+from argparse import Namespace
+from functools import lru_cache
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+VARIANT_ARGS = {
+    "small": dict(nfilter=8, tfilter=8, layers=1),
+    "xsmall": dict(nfilter=8, tfilter=8, layers=1),
+    "full": dict(nfilter=6, tfilter=10, layers=1),
+}
+
+
+def sha(a: np.ndarray) -> str:
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def args_for(variant: str) -> Namespace:
+    return Namespace(groups=[1, None, 4, None], **VARIANT_ARGS[variant])
+
+
+@lru_cache(maxsize=None)
+def golden_npz(variant: str):
+    with np.load(os.path.join(GOLD, f"ref_{variant}.npz")) as z:
+        return {k: z[k] for k in z.files}
+
+
+@lru_cache(maxsize=None)
+def golden_json(variant: str):
+    with open(os.path.join(GOLD, f"ref_luts_{variant}.json")) as f:
+        return json.load(f)
+
+
+@lru_cache(maxsize=None)
+def golden_layout(variant: str):
+    with open(os.path.join(GOLD, f"state_layout_{variant}.json")) as f:
+        return json.load(f)
+
+
+@lru_cache(maxsize=None)
+def spec_and_state(variant: str):
+    from scale_imagenet_amd.spec import make_spec
+    from scale_imagenet_amd.synth import synth_state_dict
+    spec = make_spec(variant, **VARIANT_ARGS[variant])
+    return spec, synth_state_dict(spec)
