@@ -61,11 +61,12 @@ def kernel_models(batch: int):
     for i, tag in enumerate(("f4", "f5", "f6")):
         ho = h // 2 + 1
         plane_in, plane_out = c * h * h / 8.0, c * ho * ho / 8.0
-        m[f"gate_dw.{tag}"] = ("hbm", batch * (plane_in + 2 * plane_out) + 2 * c * 8192)
-        m[f"gate_pw.{tag}"] = ("hbm", batch * (plane_in + 2 * plane_out) + (c // 16) * 131072)
+        # stage 1 = Block_conv1/2 (rows in, 2 word planes out, 2*C tables of 8 KiB) +
+        #           Block_conv3 and both majorities (words in, 2 word planes out, C/16 tables of 128 KiB)
+        m[f"gate_stage1.{tag}"] = ("hbm", batch * (2 * plane_in + 4 * plane_out) + 2 * c * 8192 + (c // 16) * 131072)
         if i < 2:
-            m[f"gate_pf.{tag}"] = ("hbm", batch * (4 * plane_out + 2 * plane_out) + (c // 4) * 65536)
-            m[f"cp_to_rp.{tag}"] = ("hbm", batch * (4 * plane_out))
+            # 4 branch planes in, the next block's input out in both layouts, C/4 tables of 64 KiB
+            m[f"gate_pf.{tag}"] = ("hbm", batch * (4 * plane_out + 2 * 2 * plane_out) + (c // 4) * 65536)
         else:
             # 4 branch tensors in, one 64-byte table row per (group, pixel), pooled floats out
             m["gate_last"] = ("hbm", batch * (4 * plane_out + (c // 4) * ho * ho * 64 + 4 * c * 16 * 4))
@@ -180,7 +181,7 @@ def main():
                 ach, peak, unit = units / (ms * 1e-3) / 1e9, HBM_PEAK_GBS, "GB/s"
             kernels.append({"kernel": k, "ms": round(ms, 5), "bound": bound, "achieved": round(ach, 3),
                             "peak": peak, "unit": unit, "frac": round(ach / peak, 5), "traffic": None})
-        gate_ms = sum(ms for k, ms in avg_ms.items() if k.startswith(("gate_dw", "gate_pw", "gate_pf", "cp_to_rp")))
+        gate_ms = sum(ms for k, ms in avg_ms.items() if k.startswith(("gate_stage1", "gate_pf")))
         gate_bytes = GATE_BYTES_PER_IMAGE * B + GATE_TABLE_BYTES
         gate = {"kernel": "gate_path (all binarised LUT launches)", "ms": round(gate_ms, 5), "bound": "hbm",
                 "achieved": round(gate_bytes / (gate_ms * 1e-3) / 1e9, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -21,7 +21,7 @@
  *
  * Packed activation layouts (all little-endian, LSB first)
  *   rows  ("RP"): uint64 [N][C][H]      bit x of word (n,c,y) is pixel (y,x); W <= 60
- *   chans ("CP"): uint16 [N][H][W][C/16] bit k of word (n,y,x,q) is channel 16q+k
+ *   chans ("CP"): uint16 [N][C/16][H][W] bit k of word (n,q,y,x) is channel 16q+k
  */
 #ifndef TTNET_H
 #define TTNET_H

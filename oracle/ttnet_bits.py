@@ -208,19 +208,19 @@ def pack_rows(bits: np.ndarray) -> np.ndarray:
 
 
 def pack_channels(bits: np.ndarray) -> np.ndarray:
-    """[N,C,H,W] bits -> channel-packed uint16 [N,H,W,C/16]; channel 16q+k is bit k."""
+    """[N,C,H,W] bits -> group-planar channel words uint16 [N,C/16,H,W]; channel 16q+k is bit k."""
     n_, c, h, w = bits.shape
     assert c % 16 == 0
     b = bits.reshape(n_, c // 16, 16, h, w).astype(np.uint16)
     sh = np.arange(16, dtype=np.uint16).reshape(1, 1, 16, 1, 1)
-    return np.transpose((b << sh).sum(axis=2, dtype=np.uint16), (0, 2, 3, 1)).copy()
+    return (b << sh).sum(axis=2, dtype=np.uint16)
 
 
 def unpack_channels(words: np.ndarray, c: int) -> np.ndarray:
-    n_, h, w, q = words.shape
-    sh = np.arange(16, dtype=np.uint16).reshape(1, 1, 1, 1, 16)
-    b = ((words[..., None] >> sh) & 1).astype(np.uint8)              # [N,H,W,Q,16]
-    return np.transpose(b.reshape(n_, h, w, q * 16), (0, 3, 1, 2))[:, :c].copy()
+    n_, q, h, w = words.shape
+    sh = np.arange(16, dtype=np.uint16).reshape(1, 1, 16, 1, 1)
+    b = ((words[:, :, None] >> sh) & 1).astype(np.uint8)             # [N,Q,16,H,W]
+    return b.reshape(n_, q * 16, h, w)[:, :c].copy()
 
 
 def unpack_rows(words: np.ndarray, w: int) -> np.ndarray:

@@ -5,12 +5,19 @@
 // (models/TT_FHE_SMALL.py:307-320).  All work here is integer / bitwise and bit exact.
 //
 // Data layout in HBM (include/ttnet.h): depthwise windows read row-packed planes
-// (uint64 per image row), the grouped 1x1 blocks read channel-packed words (uint16 = the 16
-// input channels of one group = the table index itself).  Tables are staged in LDS
-// (128 KiB per workgroup) and read with one ds_read per lookup.
+// (uint64 per image row); the grouped 1x1 blocks read group-planar channel words
+// (uint16 = the 16 input channels of one group = the table index itself).
 //
-// Bound: HBM nominally (packed activations + tables once per batch, SURVEY §8d:
-// 74,592 B/image + 14.2 MB); in practice LDS gather issue + index-forming VALU.
+// Two launches per block:
+//   stage 1  heterogeneous workgroups: "dw" units evaluate Block_conv1 / Block_conv2 for 16
+//            channels of one branch, "pw" units evaluate Block_conv3 + both 2x2 majorities
+//            for one 16-channel group.  Every unit keeps its 128 KiB of tables in LDS
+//            (staged with direct global->LDS loads) and walks a slice of the batch.
+//   stage 2  Block_convf over the four branches (two 64 KiB groups per workgroup), emitting
+//            the next block's input in both layouts (words directly, rows by ballot).
+//
+// Bound: HBM nominally (packed activations + tables once per batch, SURVEY 8(d):
+// 74,592 B/image + 14.2 MB); in practice index-forming VALU + LDS gather issue.
 
 #include "ttnet_common.h"
 
@@ -18,19 +25,32 @@ namespace ttnet {
 
 namespace {
 
-constexpr int kGateThreads = 512;
+constexpr int kGateThreads = 1024;
+constexpr int kTableLds = 131072;
 
-__device__ inline void copy_to_lds(uint8_t *dst, const uint8_t *src, size_t bytes) {
-  // bytes is a multiple of 4; both sides 4-byte aligned
-  if ((bytes & 15) == 0 && (((uintptr_t)src) & 15) == 0) {
-    const uint4 *s4 = (const uint4 *)src;
-    uint4 *d4 = (uint4 *)dst;
-    for (size_t i = threadIdx.x; i < bytes / 16; i += blockDim.x) d4[i] = s4[i];
-  } else {
-    const uint32_t *s1 = (const uint32_t *)src;
-    uint32_t *d1 = (uint32_t *)dst;
-    for (size_t i = threadIdx.x; i < bytes / 4; i += blockDim.x) d1[i] = s1[i];
+// Linear async copy global -> LDS, 16 B per lane per instruction (global_load_lds_dwordx4);
+// bytes is a multiple of 1024.  Caller waits with wait_lds_stage() before reading.
+__device__ inline void stage_lds_async(uint8_t *lds, const uint8_t *src, int bytes) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+  for (int chunk = wave; chunk < bytes / 1024; chunk += nwaves) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + (size_t)chunk * 1024 + lane * 16),
+                                     (__attribute__((address_space(3))) void *)(lds + chunk * 1024), 16, 0, 0);
   }
+}
+__device__ inline void wait_lds_stage() {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+}
+
+// Lane LANE of (lo,hi) := a wave-uniform 64-bit value (v_writelane_b32; hipcc exposes no
+// builtin).  gfx950 needs 2 wait states between a VALU write of an SGPR (the v_cmp of a
+// ballot) and a VALU read of it; hipcc pads that for its own instructions but not inside
+// an asm statement, hence the s_nop.
+template <int LANE>
+__device__ inline void writelane64(uint32_t &lo, uint32_t &hi, uint64_t sval) {
+  asm("s_nop 1\n\tv_writelane_b32 %0, %2, %4\n\tv_writelane_b32 %1, %3, %4"
+      : "+v"(lo), "+v"(hi)
+      : "s"((uint32_t)sval), "s"((uint32_t)(sval >> 32)), "n"(LANE));
 }
 
 __device__ inline uint32_t maj4(uint32_t a, uint32_t b, uint32_t c, uint32_t d) {
@@ -38,108 +58,174 @@ __device__ inline uint32_t maj4(uint32_t a, uint32_t b, uint32_t c, uint32_t d) 
   return (a & b) | (c & d) | ((a | b) & (c | d));
 }
 
-// ---- depthwise Block_conv1 / Block_conv2 ---------------------------------------------------
-// grid (C/16, 2 branches, slices); lane = (channel c = lane&15, output row slot = lane>>4).
-// Each lane walks one output row of its channel; the ballot of 64 lanes is four
-// channel-packed words (4 rows x 16 channels) of one output column.
-template <int KH, int KW>
-__global__ __launch_bounds__(kGateThreads) void gate_dw_kernel(GateBlockArgs a, int tb, int imgs_per_slice) {
-  extern __shared__ __align__(16) uint8_t lds[];
-  const int q = blockIdx.x, branch = blockIdx.y;
-  const int Q = a.C / 16;
-  const uint8_t *tab = (branch ? a.t_dw2 : a.t_dw1) + (size_t)q * 16 * tb;
-  uint16_t *out = branch ? a.o2 : a.o1;
-  copy_to_lds(lds, tab, (size_t)16 * tb);
-  __syncthreads();
+// 4-bit (KW-bit) field of a padded row (lo,hi) at constant bit offset SH
+template <int SH, int KW>
+__device__ inline uint32_t row_field(uint32_t lo, uint32_t hi) {
+  constexpr uint32_t mask = (1u << KW) - 1u;
+  if constexpr (SH + KW <= 32) return (lo >> SH) & mask;
+  else if constexpr (SH >= 32) return (hi >> (SH - 32)) & mask;
+  else return __builtin_amdgcn_alignbit(hi, lo, SH) & mask;
+}
 
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
-  const int c = lane & 15, slot = lane >> 4;
-  const int n0 = blockIdx.z * imgs_per_slice;
-  const int n1 = min(a.n, n0 + imgs_per_slice);
-  const int rows4 = (a.Ho + 3) / 4;
-  const int tasks = (n1 - n0) * rows4;
-  const uint8_t *mytab = lds + c * tb;
-  for (int t = wave; t < tasks; t += nwaves) {
-    const int n = n0 + t / rows4, oy = (t % rows4) * 4 + slot;
-    const bool valid = oy < a.Ho;
-    uint64_t row[KH];
-#pragma unroll
-    for (int kh = 0; kh < KH; ++kh) {
-      const int iy = oy * a.stride - a.pad + kh;
-      uint64_t r = 0;
-      if (valid && iy >= 0 && iy < a.H) r = a.x_rp[((size_t)n * a.C + 16 * q + c) * a.H + iy];
-      row[kh] = r << a.pad;
-    }
-    uint64_t keep = 0;
-    for (int ox = 0; ox < a.Wo; ++ox) {
-      const int sh = ox * a.stride;
+template <int KH, int KW, int STRIDE, int WO, int OX>
+struct DwCols {
+  // evaluates output columns OX..WO-1 of one output row per lane
+  __device__ static inline void run(const uint32_t (&lo)[KH], const uint32_t (&hi)[KH], const uint32_t *tab32,
+                                    uint32_t c, uint64_t vmask, uint32_t &keep_lo, uint32_t &keep_hi) {
+    if constexpr (OX < WO) {
       uint32_t idx = 0;
 #pragma unroll
-      for (int kh = 0; kh < KH; ++kh) idx |= ((uint32_t)(row[kh] >> sh) & ((1u << KW) - 1u)) << (kh * KW);
-      const uint32_t byte = mytab[idx >> 3];
-      const bool bit = valid && ((byte >> (idx & 7)) & 1u);
-      const uint64_t m = __ballot(bit);
-      if (lane == ox) keep = m;
-    }
-    if (lane < a.Wo) {
-#pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        const int oys = (t % rows4) * 4 + s;
-        if (oys < a.Ho) out[(((size_t)n * a.Ho + oys) * a.Wo + lane) * Q + q] = (uint16_t)(keep >> (16 * s));
-      }
+      for (int kh = 0; kh < KH; ++kh) idx |= row_field<OX * STRIDE, KW>(lo[kh], hi[kh]) << (kh * KW);
+      // striped table: dword w of channel c sits at [w*16 + c]
+      const uint32_t word = tab32[((idx >> 5) << 4) + c];
+      const uint64_t m = __ballot((word >> (idx & 31)) & 1u) & vmask;
+      writelane64<OX>(keep_lo, keep_hi, m);
+      DwCols<KH, KW, STRIDE, WO, OX + 1>::run(lo, hi, tab32, c, vmask, keep_lo, keep_hi);
     }
   }
-}
+};
 
-// ---- Block_conv3 (grouped 1x1, 16 -> 16 bits) + the two 2x2 majority pools ---------------
-// grid (C/16, slices); one thread per pooled pixel: four lookups, two majorities.
-__global__ __launch_bounds__(kGateThreads) void gate_pw_kernel(GateBlockArgs a, int imgs_per_slice) {
+// ---- stage 1: depthwise Block_conv1/2 units and Block_conv3+majority units --------------------
+// grid (units, slices).  dw unit u < n_dw: q = u>>1, branch = u&1.  pw unit: q = u - n_dw.
+// dw: lane = (channel c = lane&15, row slot = lane>>4); each lane walks one output row of its
+// channel; the ballot of the wave is four channel words (4 rows x 16 channels) of one column.
+template <int KH, int KW, int STRIDE, int PAD, int H, int HO>
+__global__ __launch_bounds__(kGateThreads) void gate_stage1_kernel(GateBlockArgs a, int n_dw, int ips_dw, int ips_pw) {
   extern __shared__ __align__(16) uint8_t lds[];
-  uint16_t *tab = (uint16_t *)lds;
-  const int q = blockIdx.x, Q = a.C / 16;
-  copy_to_lds(lds, (const uint8_t *)(a.t_c3 + (size_t)q * 65536), 65536 * 2);
-  __syncthreads();
-  const int Hp = a.H / 2, Wp = a.W / 2;
-  const int n0 = blockIdx.y * imgs_per_slice;
-  const int n1 = min(a.n, n0 + imgs_per_slice);
-  const int per = Hp * Wp;
-  const int tasks = (n1 - n0) * per;
-  for (int t = threadIdx.x; t < tasks; t += blockDim.x) {
-    const int n = n0 + t / per, r = t % per, py = r / Wp, px = r % Wp;
-    const uint16_t *src = a.x_cp + (((size_t)n * a.H + 2 * py) * a.W + 2 * px) * Q + q;
-    const uint32_t w0 = src[0], w1 = src[Q], w2 = src[(size_t)a.W * Q], w3 = src[(size_t)a.W * Q + Q];
-    const uint32_t r0 = tab[w0], r1 = tab[w1], r2 = tab[w2], r3 = tab[w3];
-    const size_t dst = (((size_t)n * a.Ho + py + a.off34) * a.Wo + px + a.off34) * Q + q;
-    a.o3[dst] = (uint16_t)maj4(r0, r1, r2, r3);
-    a.o4[dst] = (uint16_t)maj4(w0, w1, w2, w3);
+  constexpr int W = H, WO = HO;
+  const int Q = a.C / 16;
+  const int unit = blockIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = kGateThreads / 64;
+
+  if (unit < n_dw) {
+    const int q = unit >> 1, branch = unit & 1;
+    const int n0 = blockIdx.y * ips_dw;
+    if (n0 >= a.n) return;
+    const int n1 = min(a.n, n0 + ips_dw);
+    const uint8_t *tab = (branch ? a.t_dw2 : a.t_dw1) + (size_t)q * kTableLds;
+    uint16_t *out = branch ? a.o2 : a.o1;
+    stage_lds_async(lds, tab, kTableLds);
+
+    const uint32_t c = lane & 15, slot = lane >> 4;
+    constexpr int rows4 = (HO + 3) / 4;
+    const int tasks = (n1 - n0) * rows4;
+    auto load_rows = [&](int t, uint64_t (&r)[KH]) {
+      const int n = n0 + t / rows4, oy = (t % rows4) * 4 + (int)slot;
+#pragma unroll
+      for (int kh = 0; kh < KH; ++kh) {
+        const int iy = oy * STRIDE - PAD + kh;
+        r[kh] = (t < tasks && oy < HO && iy >= 0 && iy < H) ? a.x_rp[((size_t)n * a.C + 16 * q + c) * H + iy] : 0ull;
+      }
+    };
+    uint64_t cur[KH], nxt[KH];
+    load_rows(wave, cur);
+    wait_lds_stage();
+    const uint32_t *tab32 = (const uint32_t *)lds;
+    for (int t = wave; t < tasks; t += nwaves) {
+      load_rows(t + nwaves, nxt);                       // prefetch the next task's rows
+      const int n = n0 + t / rows4, oyb = (t % rows4) * 4;
+      const bool valid = oyb + (int)slot < HO;
+      const uint64_t vmask = __ballot(valid);
+      uint32_t lo[KH], hi[KH];
+#pragma unroll
+      for (int kh = 0; kh < KH; ++kh) {
+        const uint64_t rp = cur[kh] << PAD;
+        lo[kh] = (uint32_t)rp;
+        hi[kh] = (uint32_t)(rp >> 32);
+      }
+      uint32_t keep_lo = 0, keep_hi = 0;
+      DwCols<KH, KW, STRIDE, WO, 0>::run(lo, hi, tab32, c, vmask, keep_lo, keep_hi);
+      if (lane < WO) {
+        const uint64_t keep = ((uint64_t)keep_hi << 32) | keep_lo;
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+          if (oyb + s < HO) out[(((size_t)n * Q + q) * HO + oyb + s) * WO + lane] = (uint16_t)(keep >> (16 * s));
+      }
+#pragma unroll
+      for (int kh = 0; kh < KH; ++kh) cur[kh] = nxt[kh];
+    }
+  } else {
+    // Block_conv3 (16 -> 16 bits per pixel and group) + majority pools of conv3(x) and of x
+    const int q = unit - n_dw;
+    const int n0 = blockIdx.y * ips_pw;
+    if (n0 >= a.n) return;
+    const int n1 = min(a.n, n0 + ips_pw);
+    stage_lds_async(lds, (const uint8_t *)(a.t_c3 + (size_t)q * 65536), kTableLds);
+    wait_lds_stage();
+    const uint16_t *tab = (const uint16_t *)lds;
+    constexpr int HP = H / 2, WP = W / 2, per = HP * WP;
+    const int tasks = (n1 - n0) * per;
+    for (int t = threadIdx.x; t < tasks; t += kGateThreads) {
+      const int n = n0 + t / per, r = t % per, py = r / WP, px = r % WP;
+      const uint16_t *src = a.x_cp + (((size_t)n * Q + q) * H + 2 * py) * W + 2 * px;
+      const uint32_t w0 = src[0], w1 = src[1], w2 = src[W], w3 = src[W + 1];
+      const uint32_t r0 = tab[w0], r1 = tab[w1], r2 = tab[w2], r3 = tab[w3];
+      const size_t dst = (((size_t)n * Q + q) * HO + py + a.off34) * WO + px + a.off34;
+      a.o3[dst] = (uint16_t)maj4(r0, r1, r2, r3);
+      a.o4[dst] = (uint16_t)maj4(w0, w1, w2, w3);
+    }
   }
 }
 
-// ---- Block_convf of a binarised block (grouped 1x1 over the interleaved branches) --------
+// lane K of (klo,khi) := ballot of bit K of r, for K = 0..15
+template <int K>
+struct BitBallots {
+  __device__ static inline void run(uint32_t r, uint32_t &klo, uint32_t &khi) {
+    if constexpr (K < 16) {
+      const uint64_t m = __ballot((r >> K) & 1u);
+      writelane64<K>(klo, khi, m);
+      BitBallots<K + 1>::run(r, klo, khi);
+    }
+  }
+};
+
+// ---- stage 2: Block_convf of a binarised block ----------------------------------------------
 // The reference interleaves to channel 4c+branch (:144-147) and groups 16 of those: group g
 // reads channels 4g..4g+3 of each branch.  Internal index = nib(out1) | nib(out2)<<4 |
 // nib(out3)<<8 | nib(out4)<<12, each nibble LSB = channel 4g.  Two groups (2 x 64 KiB of
-// 8-bit entries) per workgroup produce one channel-packed output word.
-__global__ __launch_bounds__(kGateThreads) void gate_pf_kernel(GateBlockArgs a, const uint8_t *t_cf,
-                                                              uint16_t *out_cp, int imgs_per_slice) {
+// 8-bit entries) per workgroup produce one output channel word; the row layout of the same
+// 16 channels comes from 16 ballots (a wave covers whole image rows).
+template <int HO>
+__global__ __launch_bounds__(kGateThreads) void gate_pf_kernel(GateBlockArgs a, const uint8_t *t_cf, uint16_t *out_cp,
+                                                              uint64_t *out_rp, int ips) {
   extern __shared__ __align__(16) uint8_t lds[];
+  constexpr int WO = HO;
+  constexpr int LPR = WO <= 16 ? 16 : 32, RPW = 64 / LPR, chunks = (HO + RPW - 1) / RPW;
   const int j = blockIdx.x;              // output word; groups 2j, 2j+1
-  const int Q = a.C / 16, Qout = a.C / 8;
-  copy_to_lds(lds, t_cf + (size_t)(2 * j) * 65536, 2 * 65536);
-  __syncthreads();
+  const int Q = a.C / 16, Qout = a.C / 8, Cout = 2 * a.C;
+  const int n0 = blockIdx.y * ips;
+  if (n0 >= a.n) return;
+  const int n1 = min(a.n, n0 + ips);
+  stage_lds_async(lds, t_cf + (size_t)(2 * j) * 65536, kTableLds);
   const int wq = j >> 1, sh = 8 * (j & 1);
-  const int n0 = blockIdx.y * imgs_per_slice;
-  const int n1 = min(a.n, n0 + imgs_per_slice);
-  const int per = a.Ho * a.Wo;
-  const size_t base = (size_t)n0 * per;
-  const int tasks = (n1 - n0) * per;
-  for (int t = threadIdx.x; t < tasks; t += blockDim.x) {
-    const size_t pix = base + t;
-    const uint32_t b1 = (a.o1[pix * Q + wq] >> sh) & 0xFF, b2 = (a.o2[pix * Q + wq] >> sh) & 0xFF;
-    const uint32_t b3 = (a.o3[pix * Q + wq] >> sh) & 0xFF, b4 = (a.o4[pix * Q + wq] >> sh) & 0xFF;
-    const uint32_t i0 = (b1 & 15) | ((b2 & 15) << 4) | ((b3 & 15) << 8) | ((b4 & 15) << 12);
-    const uint32_t i1 = (b1 >> 4) | ((b2 >> 4) << 4) | ((b3 >> 4) << 8) | ((b4 >> 4) << 12);
-    out_cp[pix * Qout + j] = (uint16_t)(lds[i0] | ((uint32_t)lds[65536 + i1] << 8));
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = kGateThreads / 64;
+  const int sub = lane / LPR, ox = lane % LPR;
+  const int tasks = (n1 - n0) * chunks;
+  wait_lds_stage();
+  for (int t = wave; t < tasks; t += nwaves) {
+    const int n = n0 + t / chunks, oy = (t % chunks) * RPW + sub;
+    const bool valid = oy < HO && ox < WO;
+    uint32_t r = 0;
+    if (valid) {
+      const size_t pix = (((size_t)n * Q + wq) * HO + oy) * WO + ox;
+      const uint32_t b1 = (a.o1[pix] >> sh) & 0xFF, b2 = (a.o2[pix] >> sh) & 0xFF;
+      const uint32_t b3 = (a.o3[pix] >> sh) & 0xFF, b4 = (a.o4[pix] >> sh) & 0xFF;
+      const uint32_t i0 = (b1 & 15) | ((b2 & 15) << 4) | ((b3 & 15) << 8) | ((b4 & 15) << 12);
+      const uint32_t i1 = (b1 >> 4) | ((b2 >> 4) << 4) | ((b3 >> 4) << 8) | ((b4 >> 4) << 12);
+      r = lds[i0] | ((uint32_t)lds[65536 + i1] << 8);
+      out_cp[(((size_t)n * Qout + j) * HO + oy) * WO + ox] = (uint16_t)r;
+    }
+    uint32_t klo = 0, khi = 0;
+    BitBallots<0>::run(r, klo, khi);
+    if (lane < 16) {
+      const uint64_t m = ((uint64_t)khi << 32) | klo;
+#pragma unroll
+      for (int s = 0; s < RPW; ++s) {
+        const int oys = (t % chunks) * RPW + s;
+        if (oys < HO)
+          out_rp[((size_t)n * Cout + 16 * j + lane) * HO + oys] = (m >> (s * LPR)) & ((1ull << LPR) - 1ull);
+      }
+    }
   }
 }
 
@@ -162,15 +248,15 @@ __global__ __launch_bounds__(256) void gate_last_kernel(GateBlockArgs a, const f
   float v[4];
 #pragma unroll
   for (int d = 0; d < 4; ++d) {
-    const size_t pix = ((size_t)n * a.Ho + 2 * py + (d >> 1)) * a.Wo + 2 * px + (d & 1);
-    const uint32_t idx = ((a.o1[pix * Q + wq] >> sh) & 15) | (((a.o2[pix * Q + wq] >> sh) & 15) << 4) |
-                         (((a.o3[pix * Q + wq] >> sh) & 15) << 8) | (((a.o4[pix * Q + wq] >> sh) & 15) << 12);
+    const size_t pix = (((size_t)n * Q + wq) * a.Ho + 2 * py + (d >> 1)) * a.Wo + 2 * px + (d & 1);
+    const uint32_t idx = ((a.o1[pix] >> sh) & 15) | (((a.o2[pix] >> sh) & 15) << 4) |
+                         (((a.o3[pix] >> sh) & 15) << 8) | (((a.o4[pix] >> sh) & 15) << 12);
     v[d] = tab[(size_t)idx * 16 + k];
   }
   feat[task * 16 + k] = (((v[0] + v[1]) + v[2]) + v[3]) * 0.25f;
 }
 
-// ---- layout conversions --------------------------------------------------------------------
+// ---- layout conversions (parity taps and ttnet_forward_from_stem_bits only) -----------------
 __global__ void cp_to_rp_kernel(const uint16_t *cp, uint64_t *rp, int n, int C, int H, int W) {
   const int Q = C / 16;
   const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -180,7 +266,7 @@ __global__ void cp_to_rp_kernel(const uint16_t *cp, uint64_t *rp, int n, int C, 
 #pragma unroll
   for (int k = 0; k < 16; ++k) rows[k] = 0;
   for (int x = 0; x < W; ++x) {
-    const uint32_t w = cp[(((size_t)img * H + y) * W + x) * Q + q];
+    const uint32_t w = cp[(((size_t)img * Q + q) * H + y) * W + x];
 #pragma unroll
     for (int k = 0; k < 16; ++k) rows[k] |= (uint64_t)((w >> k) & 1u) << x;
   }
@@ -200,7 +286,7 @@ __global__ void rp_to_cp_kernel(const uint64_t *rp, uint16_t *cp, int n, int C, 
     uint32_t w = 0;
 #pragma unroll
     for (int k = 0; k < 16; ++k) w |= (uint32_t)((rows[k] >> x) & 1ull) << k;
-    cp[(((size_t)img * H + y) * W + x) * Q + q] = (uint16_t)w;
+    cp[(((size_t)img * Q + q) * H + y) * W + x] = (uint16_t)w;
   }
 }
 
@@ -213,14 +299,11 @@ __global__ void feat_to_ref_kernel(const float *feat, float *out, int n, int G, 
   out[img * per + ((size_t)(16 * g + k)) * PP + pp] = feat[t];
 }
 
-int slices_for(int n, int units, int *imgs_per_slice) {
-  // enough workgroups to cover the 256 CUs about twice, without slicing finer than 1 image
-  int want = (512 + units - 1) / units;
-  if (want < 1) want = 1;
-  if (want > n) want = n;
-  const int ips = (n + want - 1) / want;
-  *imgs_per_slice = ips;
-  return (n + ips - 1) / ips;
+// images per slice so that `units` table sets spread over about `target` workgroups
+int imgs_per_slice(int n, int units, int target) {
+  int slices = std::max(1, target / std::max(1, units));
+  slices = std::min(slices, n);
+  return (n + slices - 1) / slices;
 }
 
 template <typename K>
@@ -230,48 +313,51 @@ int allow_big_lds(K kernel, size_t bytes) {
   return TTNET_OK;
 }
 
+template <int H, int HO>
+int launch_stage1_t(const GateBlockArgs &a, hipStream_t s) {
+  const int n_dw = (a.C / 16) * 2, n_pw = a.C / 16;
+  const int ips_dw = imgs_per_slice(a.n, n_dw, 256), ips_pw = imgs_per_slice(a.n, n_pw, 48);
+  const int slices = std::max((a.n + ips_dw - 1) / ips_dw, (a.n + ips_pw - 1) / ips_pw);
+  auto k = gate_stage1_kernel<4, 4, 2, 2, H, HO>;
+  TT_TRY(allow_big_lds(k, kTableLds));
+  hipLaunchKernelGGL(k, dim3(n_dw + n_pw, slices), dim3(kGateThreads), kTableLds, s, a, n_dw, ips_dw, ips_pw);
+  TT_HIP(hipGetLastError());
+  return TTNET_OK;
+}
+
+template <int HO>
+int launch_pf_t(const GateBlockArgs &a, const uint8_t *t_cf, uint16_t *out_cp, uint64_t *out_rp, hipStream_t s) {
+  const int units = a.C / 8;
+  const int ips = imgs_per_slice(a.n, units, 128);
+  auto k = gate_pf_kernel<HO>;
+  TT_TRY(allow_big_lds(k, kTableLds));
+  hipLaunchKernelGGL(k, dim3(units, (a.n + ips - 1) / ips), dim3(kGateThreads), kTableLds, s, a, t_cf, out_cp, out_rp, ips);
+  TT_HIP(hipGetLastError());
+  return TTNET_OK;
+}
+
 }  // namespace
 
-int launch_gate_dw(const GateBlockArgs &a, hipStream_t s) {
-  if (a.C % 16 || a.W + 2 * a.pad > 64 || a.Wo > 64 || a.kh1 != a.kh2 || a.kw1 != a.kw2) {
-    set_error("gate_dw: unsupported geometry C=%d W=%d pad=%d", a.C, a.W, a.pad);
+int launch_gate_stage1(const GateBlockArgs &a, hipStream_t s) {
+  if (a.C % 16 || a.H != a.W || a.Ho != a.Wo || a.kh1 != 4 || a.kw1 != 4 || a.kh2 != 4 || a.kw2 != 4 || a.stride != 2 ||
+      a.pad != 2) {
+    set_error("gate_stage1: unsupported geometry C=%d %dx%d k=%dx%d", a.C, a.H, a.W, a.kh1, a.kw1);
     return TTNET_E_UNSUPPORTED;
   }
-  const int nb = a.kh1 * a.kw1;
-  const int tb = (1 << nb) >= 32 ? (1 << nb) / 8 : 4;
-  const size_t lds = (size_t)16 * tb;
-  int ips;
-  const int slices = slices_for(a.n, (a.C / 16) * 2, &ips);
-  dim3 grid(a.C / 16, 2, slices);
-  if (a.kh1 == 4 && a.kw1 == 4) {
-    TT_TRY(allow_big_lds(gate_dw_kernel<4, 4>, lds));
-    hipLaunchKernelGGL((gate_dw_kernel<4, 4>), grid, dim3(kGateThreads), lds, s, a, tb, ips);
-  } else if (a.kh1 == 2 && a.kw1 == 2) {
-    hipLaunchKernelGGL((gate_dw_kernel<2, 2>), grid, dim3(kGateThreads), lds, s, a, tb, ips);
-  } else {
-    set_error("gate_dw: no kernel for %dx%d windows", a.kh1, a.kw1);
-    return TTNET_E_UNSUPPORTED;
-  }
-  TT_HIP(hipGetLastError());
-  return TTNET_OK;
+  if (a.H == 56 && a.Ho == 29) return launch_stage1_t<56, 29>(a, s);
+  if (a.H == 29 && a.Ho == 15) return launch_stage1_t<29, 15>(a, s);
+  if (a.H == 15 && a.Ho == 8) return launch_stage1_t<15, 8>(a, s);
+  if (a.H == 8 && a.Ho == 5) return launch_stage1_t<8, 5>(a, s);
+  set_error("gate_stage1: no kernel for %dx%d -> %dx%d", a.H, a.W, a.Ho, a.Wo);
+  return TTNET_E_UNSUPPORTED;
 }
 
-int launch_gate_pw(const GateBlockArgs &a, hipStream_t s) {
-  int ips;
-  const int slices = slices_for(a.n, a.C / 16, &ips);
-  TT_TRY(allow_big_lds(gate_pw_kernel, 131072));
-  hipLaunchKernelGGL(gate_pw_kernel, dim3(a.C / 16, slices), dim3(kGateThreads), 131072, s, a, ips);
-  TT_HIP(hipGetLastError());
-  return TTNET_OK;
-}
-
-int launch_gate_pf(const GateBlockArgs &a, const uint8_t *t_cf, uint16_t *out_cp, hipStream_t s) {
-  int ips;
-  const int slices = slices_for(a.n, a.C / 8, &ips);
-  TT_TRY(allow_big_lds(gate_pf_kernel, 131072));
-  hipLaunchKernelGGL(gate_pf_kernel, dim3(a.C / 8, slices), dim3(kGateThreads), 131072, s, a, t_cf, out_cp, ips);
-  TT_HIP(hipGetLastError());
-  return TTNET_OK;
+int launch_gate_pf(const GateBlockArgs &a, const uint8_t *t_cf, uint16_t *out_cp, uint64_t *out_rp, hipStream_t s) {
+  if (a.Ho == 29) return launch_pf_t<29>(a, t_cf, out_cp, out_rp, s);
+  if (a.Ho == 15) return launch_pf_t<15>(a, t_cf, out_cp, out_rp, s);
+  if (a.Ho == 8) return launch_pf_t<8>(a, t_cf, out_cp, out_rp, s);
+  set_error("gate_pf: no kernel for %dx%d", a.Ho, a.Wo);
+  return TTNET_E_UNSUPPORTED;
 }
 
 int launch_gate_last(const GateBlockArgs &a, const float *t_last, float *feat, hipStream_t s) {

@@ -88,16 +88,16 @@ __global__ __launch_bounds__(kThreads) void lut_build_kernel(LutBuildArgs a) {
         if (o < cout_g) dst[o] = outf[o];
     }
   } else if (cout_g == 1) {
-    // bit-packed along the index: byte idx>>3, bit idx&7
+    // 1-bit entries: dword w = idx>>5, bit idx&31; the dwords of 16 consecutive groups
+    // (channels) are striped: [g/16][w][g%16], so that a workgroup's 16 tables interleave in
+    // LDS banks (gate.hip)
     const unsigned long long m = __ballot(live && (bits & 1u));
     const int lane = threadIdx.x & 63;
-    const size_t group_bytes = entries >= 32 ? entries / 8 : 4;
-    if (lane == 0) {
-      if (entries >= 64) {
-        *(unsigned long long *)((uint8_t *)a.table + g * group_bytes + idx / 8) = m;
-      } else {
-        *(unsigned *)((uint8_t *)a.table + g * group_bytes) = (unsigned)m;
-      }
+    const size_t words = entries >= 32 ? entries / 32 : 1;
+    if (lane == 0 && idx < entries) {
+      unsigned *t32 = (unsigned *)a.table + ((size_t)(g >> 4) * words * 16 + (g & 15));
+      t32[(size_t)(idx >> 5) * 16] = (unsigned)m;
+      if (entries >= 64) t32[(size_t)((idx >> 5) + 1) * 16] = (unsigned)(m >> 32);
     }
   } else if (live) {
     if (cout_g <= 8)
@@ -115,8 +115,8 @@ int launch_lut_build(const LutBuildArgs &a, hipStream_t s) {
     return TTNET_E_UNSUPPORTED;
   }
   const unsigned entries = 1u << a.n;
-  if (entries < 64 && a.cout_g == 1 && entries > 32) {
-    set_error("lut_build: 1-bit tables need 2^n <= 32 or >= 64");
+  if (a.cout_g == 1 && a.groups % 16) {
+    set_error("lut_build: depthwise tables are striped by 16 channels; groups=%d", a.groups);
     return TTNET_E_UNSUPPORTED;
   }
   dim3 grid((entries + kThreads - 1) / kThreads, a.groups);

@@ -410,21 +410,17 @@ GateBlockArgs gate_args(ttnet_plan *pl, size_t i, int n) {
   return a;
 }
 
-static const char *kDwNames[] = {"gate_dw.f4", "gate_dw.f5", "gate_dw.f6", "gate_dw.f7"};
-static const char *kPwNames[] = {"gate_pw.f4", "gate_pw.f5", "gate_pw.f6", "gate_pw.f7"};
+static const char *kS1Names[] = {"gate_stage1.f4", "gate_stage1.f5", "gate_stage1.f6", "gate_stage1.f7"};
 static const char *kPfNames[] = {"gate_pf.f4", "gate_pf.f5", "gate_pf.f6", "gate_pf.f7"};
-static const char *kTrNames[] = {"cp_to_rp.f4", "cp_to_rp.f5", "cp_to_rp.f6", "cp_to_rp.f7"};
 
 int run_from_blocks(ttnet_plan *pl, int n, float *logits, hipStream_t s) {
   for (size_t i = 0; i < pl->blocks.size(); ++i) {
     MultiHead &mh = pl->blocks[i];
     GateBlockArgs a = gate_args(pl, i, n);
-    TT_TIMED(pl, kDwNames[i], s, launch_gate_dw(a, s));
-    TT_TIMED(pl, kPwNames[i], s, launch_gate_pw(a, s));
+    TT_TIMED(pl, kS1Names[i], s, launch_gate_stage1(a, s));
     if (!mh.last) {
-      TT_TIMED(pl, kPfNames[i], s, launch_gate_pf(a, (const uint8_t *)mh.cf.table, pl->x_cp[i + 1], s));
-      TT_TIMED(pl, kTrNames[i], s,
-               launch_cp_to_rp(pl->x_cp[i + 1], pl->x_rp[i + 1], n, mh.cf.g.out_planes, mh.Ho, mh.Wo, s));
+      TT_TIMED(pl, kPfNames[i], s,
+               launch_gate_pf(a, (const uint8_t *)mh.cf.table, pl->x_cp[i + 1], pl->x_rp[i + 1], s));
     } else {
       TT_TIMED(pl, "gate_last", s, launch_gate_last(a, (const float *)mh.cf.table, pl->feat, s));
     }
@@ -687,7 +683,8 @@ int ttnet_plan_get_table(ttnet_plan *pl, const char *name, void *dst_host, size_
   std::vector<uint8_t> raw(g.table_bytes());
   TT_HIP(hipMemcpy(raw.data(), b->table, raw.size(), hipMemcpyDeviceToHost));
   const int cg = g.cout_g(), eb = g.entry_bits();
-  const size_t group_bytes_1 = entries >= 32 ? entries / 8 : 4;
+  const size_t words_1 = entries >= 32 ? entries / 32 : 1;   // striped 1-bit layout: [grp/16][w][grp%16]
+  const uint32_t *raw32 = (const uint32_t *)raw.data();
   for (int grp = 0; grp < g.groups; ++grp)
     for (uint32_t idx = 0; idx < entries; ++idx) {
       const size_t ci = canonical_index(*b, idx);
@@ -697,7 +694,7 @@ int ttnet_plan_get_table(ttnet_plan *pl, const char *name, void *dst_host, size_
         continue;
       }
       uint32_t bits;
-      if (eb == 1) bits = (raw[grp * group_bytes_1 + (idx >> 3)] >> (idx & 7)) & 1u;
+      if (eb == 1) bits = (raw32[((size_t)(grp >> 4) * words_1 + (idx >> 5)) * 16 + (grp & 15)] >> (idx & 31)) & 1u;
       else if (eb == 8) bits = raw[(size_t)grp * entries + idx];
       else bits = ((const uint16_t *)raw.data())[(size_t)grp * entries + idx];
       uint8_t *d = (uint8_t *)dst_host + ((size_t)grp * entries + ci) * cg;
@@ -725,7 +722,8 @@ int ttnet_plan_set_table(ttnet_plan *pl, const char *name, const void *src_host,
   }
   std::vector<uint8_t> raw(g.table_bytes(), 0);
   const int cg = g.cout_g(), eb = g.entry_bits();
-  const size_t group_bytes_1 = entries >= 32 ? entries / 8 : 4;
+  const size_t words_1 = entries >= 32 ? entries / 32 : 1;
+  uint32_t *raw32 = (uint32_t *)raw.data();
   for (int grp = 0; grp < g.groups; ++grp)
     for (uint32_t idx = 0; idx < entries; ++idx) {
       const size_t ci = canonical_index(*b, idx);
@@ -737,7 +735,7 @@ int ttnet_plan_set_table(ttnet_plan *pl, const char *name, const void *src_host,
       const uint8_t *sp = (const uint8_t *)src_host + ((size_t)grp * entries + ci) * cg;
       uint32_t bits = 0;
       for (int o = 0; o < cg; ++o) bits |= (uint32_t)(sp[o] & 1u) << o;
-      if (eb == 1) raw[grp * group_bytes_1 + (idx >> 3)] |= (uint8_t)(bits << (idx & 7));
+      if (eb == 1) raw32[((size_t)(grp >> 4) * words_1 + (idx >> 5)) * 16 + (grp & 15)] |= bits << (idx & 31);
       else if (eb == 8) raw[(size_t)grp * entries + idx] = (uint8_t)bits;
       else ((uint16_t *)raw.data())[(size_t)grp * entries + idx] = (uint16_t)bits;
     }

@@ -81,7 +81,7 @@ __global__ __launch_bounds__(256) void stem_kernel(const float *__restrict__ x, 
         if (lane == r * 16 + j) keep = m;
         word |= (bit ? 1u : 0u) << j;
       }
-      if (lane < 56) cp[(((size_t)n * 56 + oy0 + r) * 56 + lane) * ngroups + grp] = (uint16_t)word;
+      if (lane < 56) cp[(((size_t)n * ngroups + grp) * 56 + oy0 + r) * 56 + lane] = (uint16_t)word;
     }
     // lane L holds the row word of channel grp*16 + (L&15), output row oy0 + (L>>4)
     rp[((size_t)n * p + grp * 16 + (lane & 15)) * 56 + oy0 + (lane >> 4)] = keep;

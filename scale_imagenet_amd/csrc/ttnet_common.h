@@ -78,15 +78,16 @@ struct GateBlockArgs {
   int off34;             // left/top zero padding of out3/out4 (1 at W=56, else 0)
   int kh1, kw1, kh2, kw2, stride, pad;
   const uint64_t *x_rp;  // [n][C][H]
-  const uint16_t *x_cp;  // [n][H][W][C/16]
-  const uint8_t *t_dw1, *t_dw2;   // [C][2^n/8]
+  const uint16_t *x_cp;  // [n][C/16][H][W]
+  const uint8_t *t_dw1, *t_dw2;   // [C/16][2^n/32][16] dwords: 16 channels striped per dword
   const uint16_t *t_c3;           // [C/16][65536]
-  uint16_t *o1, *o2, *o3, *o4;    // [n][Ho][Wo][C/16]
+  uint16_t *o1, *o2, *o3, *o4;    // [n][C/16][Ho][Wo]
 };
-int launch_gate_dw(const GateBlockArgs &a, hipStream_t s);
-int launch_gate_pw(const GateBlockArgs &a, hipStream_t s);
-// convf of a non-last block: 4 branch tensors -> CP [n][Ho][Wo][Cout/16], Cout = 8 * (4C/16)
-int launch_gate_pf(const GateBlockArgs &a, const uint8_t *t_cf, uint16_t *out_cp, hipStream_t s);
+// stage 1: Block_conv1, Block_conv2 (depthwise) and Block_conv3 + both majority pools
+int launch_gate_stage1(const GateBlockArgs &a, hipStream_t s);
+// stage 2: convf of a non-last block: 4 branch tensors -> words [n][Cout/16][Ho][Wo] and rows
+// [n][Cout][Ho], Cout = 8 * (4C/16)
+int launch_gate_pf(const GateBlockArgs &a, const uint8_t *t_cf, uint16_t *out_cp, uint64_t *out_rp, hipStream_t s);
 // convf of the last block through the float table: -> feat [n][4C/16][pooled][16]
 int launch_gate_last(const GateBlockArgs &a, const float *t_last, float *feat, hipStream_t s);
 int launch_cp_to_rp(const uint16_t *cp, uint64_t *rp, int n, int C, int H, int W, hipStream_t s);
