@@ -19,6 +19,8 @@
 // Bound: HBM nominally (packed activations + tables once per batch, SURVEY 8(d):
 // 74,592 B/image + 14.2 MB); in practice index-forming VALU + LDS gather issue.
 
+#include <type_traits>
+
 #include "ttnet_common.h"
 
 namespace ttnet {
@@ -67,23 +69,35 @@ __device__ inline uint32_t row_field(uint32_t lo, uint32_t hi) {
   else return __builtin_amdgcn_alignbit(hi, lo, SH) & mask;
 }
 
-template <int KH, int KW, int STRIDE, int WO, int OX>
-struct DwCols {
-  // evaluates output columns OX..WO-1 of one output row per lane
-  __device__ static inline void run(const uint32_t (&lo)[KH], const uint32_t (&hi)[KH], const uint32_t *tab32,
-                                    uint32_t c, uint64_t vmask, uint32_t &keep_lo, uint32_t &keep_hi) {
-    if constexpr (OX < WO) {
-      uint32_t idx = 0;
-#pragma unroll
-      for (int kh = 0; kh < KH; ++kh) idx |= row_field<OX * STRIDE, KW>(lo[kh], hi[kh]) << (kh * KW);
-      // striped table: dword w of channel c sits at [w*16 + c]
-      const uint32_t word = tab32[((idx >> 5) << 4) + c];
-      const uint64_t m = __ballot((word >> (idx & 31)) & 1u) & vmask;
-      writelane64<OX>(keep_lo, keep_hi, m);
-      DwCols<KH, KW, STRIDE, WO, OX + 1>::run(lo, hi, tab32, c, vmask, keep_lo, keep_hi);
-    }
+// compile-time loop: f(integral_constant<int, I>) for I in [0, N)
+template <int I, int N, typename F>
+__device__ inline void static_for(F &&f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, N>(f);
   }
-};
+}
+
+// One output row per lane, all WO columns: first every window index and its table read are
+// issued (WO independent ds_reads in flight), then the bits are balloted column by column.
+template <int KH, int KW, int STRIDE, int WO>
+__device__ inline void dw_row(const uint32_t (&lo)[KH], const uint32_t (&hi)[KH], const uint32_t *tab32, uint32_t c,
+                              uint32_t &keep_lo, uint32_t &keep_hi) {
+  uint32_t word[WO], sel[WO];
+  static_for<0, WO>([&](auto ox) {
+    constexpr int OX = decltype(ox)::value;
+    uint32_t idx = 0;
+#pragma unroll
+    for (int kh = 0; kh < KH; ++kh) idx |= row_field<OX * STRIDE, KW>(lo[kh], hi[kh]) << (kh * KW);
+    sel[OX] = idx;
+    word[OX] = tab32[((idx >> 5) << 4) + c];      // striped table: dword w of channel c at [w*16 + c]
+  });
+  static_for<0, WO>([&](auto ox) {
+    constexpr int OX = decltype(ox)::value;
+    const uint64_t m = __ballot((word[OX] >> (sel[OX] & 31)) & 1u);
+    writelane64<OX>(keep_lo, keep_hi, m);
+  });
+}
 
 // ---- stage 1: depthwise Block_conv1/2 units and Block_conv3+majority units --------------------
 // grid (units, slices).  dw unit u < n_dw: q = u>>1, branch = u&1.  pw unit: q = u - n_dw.
@@ -134,9 +148,9 @@ __global__ __launch_bounds__(kGateThreads) void gate_stage1_kernel(GateBlockArgs
         hi[kh] = (uint32_t)(rp >> 32);
       }
       uint32_t keep_lo = 0, keep_hi = 0;
-      DwCols<KH, KW, STRIDE, WO, 0>::run(lo, hi, tab32, c, vmask, keep_lo, keep_hi);
+      dw_row<KH, KW, STRIDE, WO>(lo, hi, tab32, c, keep_lo, keep_hi);
       if (lane < WO) {
-        const uint64_t keep = ((uint64_t)keep_hi << 32) | keep_lo;
+        const uint64_t keep = (((uint64_t)keep_hi << 32) | keep_lo) & vmask;   // rows past HO: no bits
 #pragma unroll
         for (int s = 0; s < 4; ++s)
           if (oyb + s < HO) out[(((size_t)n * Q + q) * HO + oyb + s) * WO + lane] = (uint16_t)(keep >> (16 * s));
@@ -153,16 +167,34 @@ __global__ __launch_bounds__(kGateThreads) void gate_stage1_kernel(GateBlockArgs
     stage_lds_async(lds, (const uint8_t *)(a.t_c3 + (size_t)q * 65536), kTableLds);
     wait_lds_stage();
     const uint16_t *tab = (const uint16_t *)lds;
-    constexpr int HP = H / 2, WP = W / 2, per = HP * WP;
+    constexpr int HP = H / 2, WP = W / 2, per = HP * WP, U = 4;
     const int tasks = (n1 - n0) * per;
-    for (int t = threadIdx.x; t < tasks; t += kGateThreads) {
-      const int n = n0 + t / per, r = t % per, py = r / WP, px = r % WP;
-      const uint16_t *src = a.x_cp + (((size_t)n * Q + q) * H + 2 * py) * W + 2 * px;
-      const uint32_t w0 = src[0], w1 = src[1], w2 = src[W], w3 = src[W + 1];
-      const uint32_t r0 = tab[w0], r1 = tab[w1], r2 = tab[w2], r3 = tab[w3];
-      const size_t dst = (((size_t)n * Q + q) * HO + py + a.off34) * WO + px + a.off34;
-      a.o3[dst] = (uint16_t)maj4(r0, r1, r2, r3);
-      a.o4[dst] = (uint16_t)maj4(w0, w1, w2, w3);
+    // U pooled pixels per thread and trip: 4U global loads, then 4U table reads, in flight together
+    for (int t0 = threadIdx.x; t0 < tasks; t0 += U * kGateThreads) {
+      uint32_t w[U][4];
+      size_t dst[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int t = t0 + u * kGateThreads;
+        const bool live = t < tasks;
+        const int tt = live ? t : 0;
+        const int n = n0 + tt / per, r = tt % per, py = r / WP, px = r % WP;
+        const uint16_t *src = a.x_cp + (((size_t)n * Q + q) * H + 2 * py) * W + 2 * px;
+        w[u][0] = src[0]; w[u][1] = src[1]; w[u][2] = src[W]; w[u][3] = src[W + 1];
+        dst[u] = live ? (((size_t)n * Q + q) * HO + py + a.off34) * WO + px + a.off34 : (size_t)-1;
+      }
+      uint32_t r[U][4];
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int d = 0; d < 4; ++d) r[u][d] = tab[w[u][d]];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        if (dst[u] != (size_t)-1) {
+          a.o3[dst[u]] = (uint16_t)maj4(r[u][0], r[u][1], r[u][2], r[u][3]);
+          a.o4[dst[u]] = (uint16_t)maj4(w[u][0], w[u][1], w[u][2], w[u][3]);
+        }
+      }
     }
   }
 }
@@ -201,18 +233,29 @@ __global__ __launch_bounds__(kGateThreads) void gate_pf_kernel(GateBlockArgs a, 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = kGateThreads / 64;
   const int sub = lane / LPR, ox = lane % LPR;
   const int tasks = (n1 - n0) * chunks;
+  auto load_words = [&](int t, uint32_t (&b)[4], size_t &pix, bool &valid) {
+    const int n = n0 + t / chunks, oy = (t % chunks) * RPW + sub;
+    valid = t < tasks && oy < HO && ox < WO;
+    pix = (((size_t)n * Q + wq) * HO + oy) * WO + ox;
+    b[0] = valid ? a.o1[pix] : 0; b[1] = valid ? a.o2[pix] : 0;
+    b[2] = valid ? a.o3[pix] : 0; b[3] = valid ? a.o4[pix] : 0;
+  };
+  uint32_t cur[4], nxt[4];
+  size_t pix, pix_n;
+  bool valid, valid_n;
+  load_words(wave, cur, pix, valid);
   wait_lds_stage();
   for (int t = wave; t < tasks; t += nwaves) {
-    const int n = n0 + t / chunks, oy = (t % chunks) * RPW + sub;
-    const bool valid = oy < HO && ox < WO;
+    load_words(t + nwaves, nxt, pix_n, valid_n);          // prefetch the next task's words
+    const int n = n0 + t / chunks;
     uint32_t r = 0;
     if (valid) {
-      const size_t pix = (((size_t)n * Q + wq) * HO + oy) * WO + ox;
-      const uint32_t b1 = (a.o1[pix] >> sh) & 0xFF, b2 = (a.o2[pix] >> sh) & 0xFF;
-      const uint32_t b3 = (a.o3[pix] >> sh) & 0xFF, b4 = (a.o4[pix] >> sh) & 0xFF;
+      const uint32_t b1 = (cur[0] >> sh) & 0xFF, b2 = (cur[1] >> sh) & 0xFF;
+      const uint32_t b3 = (cur[2] >> sh) & 0xFF, b4 = (cur[3] >> sh) & 0xFF;
       const uint32_t i0 = (b1 & 15) | ((b2 & 15) << 4) | ((b3 & 15) << 8) | ((b4 & 15) << 12);
       const uint32_t i1 = (b1 >> 4) | ((b2 >> 4) << 4) | ((b3 >> 4) << 8) | ((b4 >> 4) << 12);
       r = lds[i0] | ((uint32_t)lds[65536 + i1] << 8);
+      const int oy = (t % chunks) * RPW + sub;
       out_cp[(((size_t)n * Qout + j) * HO + oy) * WO + ox] = (uint16_t)r;
     }
     uint32_t klo = 0, khi = 0;
@@ -226,6 +269,10 @@ __global__ __launch_bounds__(kGateThreads) void gate_pf_kernel(GateBlockArgs a, 
           out_rp[((size_t)n * Cout + 16 * j + lane) * HO + oys] = (m >> (s * LPR)) & ((1ull << LPR) - 1ull);
       }
     }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) cur[i] = nxt[i];
+    pix = pix_n;
+    valid = valid_n;
   }
 }
 
@@ -315,8 +362,10 @@ int allow_big_lds(K kernel, size_t bytes) {
 
 template <int H, int HO>
 int launch_stage1_t(const GateBlockArgs &a, hipStream_t s) {
+  // One round of workgroups (1 per CU, 128 KiB LDS each): the depthwise units carry ~95 % of
+  // the work and get ~7/8 of the CUs; the conv3 units take the rest and finish early.
   const int n_dw = (a.C / 16) * 2, n_pw = a.C / 16;
-  const int ips_dw = imgs_per_slice(a.n, n_dw, 256), ips_pw = imgs_per_slice(a.n, n_pw, 48);
+  const int ips_dw = imgs_per_slice(a.n, n_dw, 224), ips_pw = imgs_per_slice(a.n, n_pw, 32);
   const int slices = std::max((a.n + ips_dw - 1) / ips_dw, (a.n + ips_pw - 1) / ips_pw);
   auto k = gate_stage1_kernel<4, 4, 2, 2, H, HO>;
   TT_TRY(allow_big_lds(k, kTableLds));
@@ -328,7 +377,7 @@ int launch_stage1_t(const GateBlockArgs &a, hipStream_t s) {
 template <int HO>
 int launch_pf_t(const GateBlockArgs &a, const uint8_t *t_cf, uint16_t *out_cp, uint64_t *out_rp, hipStream_t s) {
   const int units = a.C / 8;
-  const int ips = imgs_per_slice(a.n, units, 128);
+  const int ips = imgs_per_slice(a.n, units, 256);
   auto k = gate_pf_kernel<HO>;
   TT_TRY(allow_big_lds(k, kTableLds));
   hipLaunchKernelGGL(k, dim3(units, (a.n + ips - 1) / ips), dim3(kGateThreads), kTableLds, s, a, t_cf, out_cp, out_rp, ips);
