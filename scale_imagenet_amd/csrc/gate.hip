@@ -19,6 +19,7 @@
 // Bound: HBM nominally (packed activations + tables once per batch, SURVEY 8(d):
 // 74,592 B/image + 14.2 MB); in practice index-forming VALU + LDS gather issue.
 
+#include <stdlib.h>
 #include <type_traits>
 
 #include "ttnet_common.h"
@@ -99,21 +100,103 @@ __device__ inline void dw_row(const uint32_t (&lo)[KH], const uint32_t (&hi)[KH]
   });
 }
 
+// ---- fast path for 4x4 / stride 2 / pad 2 windows (the small model) -----------------------
+// A lane owns one (channel, output row).  Columns are evaluated in pairs (p, p+8): column
+// p+8 is the same window 16 bits further along the rows, so with the four padded rows
+// pre-shifted by 4*kh one funnel shift per row yields the nibbles of BOTH windows, already
+// in place, in the low and high half of a register:
+//     idx2 = (A0 & 0x000F000F) | (A1 & 0x00F000F0) | (A2 & 0x0F000F00) | (A3 & 0xF000F000)
+// Each lane accumulates its own output row (bit x = column x); the 16 lanes of a channel
+// group then transpose their 16x16 bit blocks in registers (4 butterfly stages, both
+// halves at once) so that lane j holds the channel words of columns j and 16+j.
+struct DwLaneConst {
+  uint32_t c4;          // byte offset of this lane's channel inside a striped table row
+  uint32_t rot[4];      // funnel-rotate amount of butterfly stage s = 8,4,2,1
+  uint32_t keep[4];     // bits this lane keeps in stage s
+};
+
+__device__ inline DwLaneConst dw_lane_const(uint32_t lane) {
+  DwLaneConst k;
+  k.c4 = (lane & 15) << 2;
+  constexpr uint32_t M[4] = {0x00FF00FFu, 0x0F0F0F0Fu, 0x33333333u, 0x55555555u};   // bit positions with (pos & s) == 0
+  constexpr uint32_t S[4] = {8, 4, 2, 1};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const bool low = (lane & S[i]) == 0;
+    k.rot[i] = low ? 32 - S[i] : S[i];          // low lane takes partner << s, high lane partner >> s
+    k.keep[i] = low ? M[i] : ~M[i];
+  }
+  return k;
+}
+
+template <int P, bool HIGH_HALF>
+__device__ inline void dw_pair(const uint32_t (&d)[4][3], const uint32_t *tab32_bytes, uint32_t c4, uint32_t &acc) {
+  // shift of the pair base column P: 2P bits; funnel over dwords (j, j+1)
+  constexpr int SH = 2 * P, J = SH / 32, R = SH % 32;
+  uint32_t idx2;
+  {
+    const uint32_t a0 = R ? __builtin_amdgcn_alignbit(d[0][J + 1], d[0][J], R) : d[0][J];
+    const uint32_t a1 = R ? __builtin_amdgcn_alignbit(d[1][J + 1], d[1][J], R) : d[1][J];
+    const uint32_t a2 = R ? __builtin_amdgcn_alignbit(d[2][J + 1], d[2][J], R) : d[2][J];
+    const uint32_t a3 = R ? __builtin_amdgcn_alignbit(d[3][J + 1], d[3][J], R) : d[3][J];
+    idx2 = (a0 & 0x000F000Fu) | (a1 & 0x00F000F0u) | (a2 & 0x0F000F00u) | (a3 & 0xF000F000u);
+  }
+  const uint8_t *tb = (const uint8_t *)tab32_bytes;
+  // striped table: dword (idx>>5) of channel c at byte ((idx>>5)*16 + c)*4
+  const uint32_t w_lo = *(const uint32_t *)(tb + (((idx2 & 0xFFE0u) << 1) | c4));
+  acc |= ((w_lo >> (idx2 & 31u)) & 1u) << P;
+  if constexpr (HIGH_HALF) {
+    const uint32_t w_hi = *(const uint32_t *)(tb + (((idx2 >> 15) & 0x1FFC0u) | c4));
+    acc |= ((w_hi >> ((idx2 >> 16) & 31u)) & 1u) << (P + 8);
+  }
+}
+
+// rows: the lane's four input rows (bit x = column x); returns the channel words of columns
+// (lane&15) [low half] and 16 + (lane&15) [high half] of this lane's output row.
+template <int WO>
+__device__ inline uint32_t dw_row_4x4s2(const uint64_t (&rows)[4], const uint32_t *tab32, const DwLaneConst &k) {
+  uint32_t d[4][3];
+#pragma unroll
+  for (int kh = 0; kh < 4; ++kh) {
+    // padded row (2 zero columns on the left) shifted left by 4*kh: up to 60 + 2 + 12 = 74 bits
+    const uint32_t lo = (uint32_t)rows[kh], hi = (uint32_t)(rows[kh] >> 32);
+    const int sh = 2 + 4 * kh;
+    d[kh][0] = lo << sh;
+    d[kh][1] = __builtin_amdgcn_alignbit(hi, lo, 32 - sh);
+    d[kh][2] = hi >> (32 - sh);
+  }
+  uint32_t acc = 0;
+  static_for<0, 8>([&](auto p) { dw_pair<decltype(p)::value, (WO > 8)>(d, tab32, k.c4, acc); });
+  if constexpr (WO > 16) static_for<16, 24>([&](auto p) { dw_pair<decltype(p)::value, (WO > 24)>(d, tab32, k.c4, acc); });
+  // 16x16 bit transpose across the 16 lanes of the channel group, both halves at once
+  constexpr int S[4] = {8, 4, 2, 1};
+  static_for<0, 4>([&](auto i) {
+    constexpr int I = decltype(i)::value;
+    const uint32_t partner = (uint32_t)__builtin_amdgcn_ds_swizzle((int)acc, 0x1F | (S[I] << 10));
+    const uint32_t moved = __builtin_amdgcn_alignbit(partner, partner, k.rot[I]);
+    acc = (acc & k.keep[I]) | (moved & ~k.keep[I]);
+  });
+  return acc;
+}
+
 // ---- stage 1: depthwise Block_conv1/2 units and Block_conv3+majority units --------------------
-// grid (units, slices).  dw unit u < n_dw: q = u>>1, branch = u&1.  pw unit: q = u - n_dw.
+// 1-D grid: blocks [0, n_dw*slices_dw) are depthwise units (unit u = b % n_dw: q = u>>1,
+// branch = u&1; slice = b / n_dw) and are dispatched first; the remaining blocks are conv3
+// units (q = b' % n_pw, slice = b' / n_pw), short, and fill CUs as depthwise blocks retire.
 // dw: lane = (channel c = lane&15, row slot = lane>>4); each lane walks one output row of its
 // channel; the ballot of the wave is four channel words (4 rows x 16 channels) of one column.
 template <int KH, int KW, int STRIDE, int PAD, int H, int HO>
-__global__ __launch_bounds__(kGateThreads) void gate_stage1_kernel(GateBlockArgs a, int n_dw, int ips_dw, int ips_pw) {
+__global__ __launch_bounds__(kGateThreads) void gate_stage1_kernel(GateBlockArgs a, int n_dw, int dw_blocks, int ips_dw,
+                                                                  int ips_pw) {
   extern __shared__ __align__(16) uint8_t lds[];
   constexpr int W = H, WO = HO;
   const int Q = a.C / 16;
-  const int unit = blockIdx.x;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = kGateThreads / 64;
 
-  if (unit < n_dw) {
+  if ((int)blockIdx.x < dw_blocks) {
+    const int unit = blockIdx.x % n_dw;
     const int q = unit >> 1, branch = unit & 1;
-    const int n0 = blockIdx.y * ips_dw;
+    const int n0 = (blockIdx.x / n_dw) * ips_dw;
     if (n0 >= a.n) return;
     const int n1 = min(a.n, n0 + ips_dw);
     const uint8_t *tab = (branch ? a.t_dw2 : a.t_dw1) + (size_t)q * kTableLds;
@@ -133,35 +216,46 @@ __global__ __launch_bounds__(kGateThreads) void gate_stage1_kernel(GateBlockArgs
     };
     uint64_t cur[KH], nxt[KH];
     load_rows(wave, cur);
+    [[maybe_unused]] const DwLaneConst lk = dw_lane_const(lane);
     wait_lds_stage();
     const uint32_t *tab32 = (const uint32_t *)lds;
     for (int t = wave; t < tasks; t += nwaves) {
       load_rows(t + nwaves, nxt);                       // prefetch the next task's rows
       const int n = n0 + t / rows4, oyb = (t % rows4) * 4;
       const bool valid = oyb + (int)slot < HO;
-      const uint64_t vmask = __ballot(valid);
-      uint32_t lo[KH], hi[KH];
+      if constexpr (KH == 4 && KW == 4 && STRIDE == 2 && PAD == 2 && WO <= 32) {
+        const uint32_t words = dw_row_4x4s2<WO>(cur, tab32, lk);
+        if (valid) {
+          uint16_t *dst = out + (((size_t)n * Q + q) * HO + oyb + slot) * WO;
+          if (c < WO) dst[c] = (uint16_t)words;
+          if (16 + c < WO) dst[16 + c] = (uint16_t)(words >> 16);
+        }
+      } else {
+        const uint64_t vmask = __ballot(valid);
+        uint32_t lo[KH], hi[KH];
 #pragma unroll
-      for (int kh = 0; kh < KH; ++kh) {
-        const uint64_t rp = cur[kh] << PAD;
-        lo[kh] = (uint32_t)rp;
-        hi[kh] = (uint32_t)(rp >> 32);
-      }
-      uint32_t keep_lo = 0, keep_hi = 0;
-      dw_row<KH, KW, STRIDE, WO>(lo, hi, tab32, c, keep_lo, keep_hi);
-      if (lane < WO) {
-        const uint64_t keep = (((uint64_t)keep_hi << 32) | keep_lo) & vmask;   // rows past HO: no bits
+        for (int kh = 0; kh < KH; ++kh) {
+          const uint64_t rp = cur[kh] << PAD;
+          lo[kh] = (uint32_t)rp;
+          hi[kh] = (uint32_t)(rp >> 32);
+        }
+        uint32_t keep_lo = 0, keep_hi = 0;
+        dw_row<KH, KW, STRIDE, WO>(lo, hi, tab32, c, keep_lo, keep_hi);
+        if (lane < WO) {
+          const uint64_t keep = (((uint64_t)keep_hi << 32) | keep_lo) & vmask;   // rows past HO: no bits
 #pragma unroll
-        for (int s = 0; s < 4; ++s)
-          if (oyb + s < HO) out[(((size_t)n * Q + q) * HO + oyb + s) * WO + lane] = (uint16_t)(keep >> (16 * s));
+          for (int s = 0; s < 4; ++s)
+            if (oyb + s < HO) out[(((size_t)n * Q + q) * HO + oyb + s) * WO + lane] = (uint16_t)(keep >> (16 * s));
+        }
       }
 #pragma unroll
       for (int kh = 0; kh < KH; ++kh) cur[kh] = nxt[kh];
     }
   } else {
     // Block_conv3 (16 -> 16 bits per pixel and group) + majority pools of conv3(x) and of x
-    const int q = unit - n_dw;
-    const int n0 = blockIdx.y * ips_pw;
+    const int b = blockIdx.x - dw_blocks;
+    const int q = b % Q;
+    const int n0 = (b / Q) * ips_pw;
     if (n0 >= a.n) return;
     const int n1 = min(a.n, n0 + ips_pw);
     stage_lds_async(lds, (const uint8_t *)(a.t_c3 + (size_t)q * 65536), kTableLds);
@@ -362,14 +456,15 @@ int allow_big_lds(K kernel, size_t bytes) {
 
 template <int H, int HO>
 int launch_stage1_t(const GateBlockArgs &a, hipStream_t s) {
-  // One round of workgroups (1 per CU, 128 KiB LDS each): the depthwise units carry ~95 % of
-  // the work and get ~7/8 of the CUs; the conv3 units take the rest and finish early.
+  // 1 workgroup per CU (128 KiB of tables in LDS).  The depthwise units carry ~95 % of the
+  // work: they get one round of the chip; the conv3 units are latency bound, so they are cut
+  // fine (more blocks in flight) and run in the shadow of the depthwise tail.
   const int n_dw = (a.C / 16) * 2, n_pw = a.C / 16;
-  const int ips_dw = imgs_per_slice(a.n, n_dw, 224), ips_pw = imgs_per_slice(a.n, n_pw, 32);
-  const int slices = std::max((a.n + ips_dw - 1) / ips_dw, (a.n + ips_pw - 1) / ips_pw);
+  const int ips_dw = imgs_per_slice(a.n, n_dw, 232), ips_pw = imgs_per_slice(a.n, n_pw, 192);
+  const int dw_blocks = n_dw * ((a.n + ips_dw - 1) / ips_dw), pw_blocks = n_pw * ((a.n + ips_pw - 1) / ips_pw);
   auto k = gate_stage1_kernel<4, 4, 2, 2, H, HO>;
   TT_TRY(allow_big_lds(k, kTableLds));
-  hipLaunchKernelGGL(k, dim3(n_dw + n_pw, slices), dim3(kGateThreads), kTableLds, s, a, n_dw, ips_dw, ips_pw);
+  hipLaunchKernelGGL(k, dim3(dw_blocks + pw_blocks), dim3(kGateThreads), kTableLds, s, a, n_dw, dw_blocks, ips_dw, ips_pw);
   TT_HIP(hipGetLastError());
   return TTNET_OK;
 }

@@ -83,7 +83,7 @@ struct GateBlockArgs {
   const uint16_t *t_c3;           // [C/16][65536]
   uint16_t *o1, *o2, *o3, *o4;    // [n][C/16][Ho][Wo]
 };
-// stage 1: Block_conv1, Block_conv2 (depthwise) and Block_conv3 + both majority pools
+// stage 1: Block_conv1, Block_conv2 (depthwise units) and Block_conv3 + both majority pools
 int launch_gate_stage1(const GateBlockArgs &a, hipStream_t s);
 // stage 2: convf of a non-last block: 4 branch tensors -> words [n][Cout/16][Ho][Wo] and rows
 // [n][Cout][Ho], Cout = 8 * (4C/16)
