@@ -45,17 +45,6 @@ __device__ inline void wait_lds_stage() {
   __syncthreads();
 }
 
-// Lane LANE of (lo,hi) := a wave-uniform 64-bit value (v_writelane_b32; hipcc exposes no
-// builtin).  gfx950 needs 2 wait states between a VALU write of an SGPR (the v_cmp of a
-// ballot) and a VALU read of it; hipcc pads that for its own instructions but not inside
-// an asm statement, hence the s_nop.
-template <int LANE>
-__device__ inline void writelane64(uint32_t &lo, uint32_t &hi, uint64_t sval) {
-  asm("s_nop 1\n\tv_writelane_b32 %0, %2, %4\n\tv_writelane_b32 %1, %3, %4"
-      : "+v"(lo), "+v"(hi)
-      : "s"((uint32_t)sval), "s"((uint32_t)(sval >> 32)), "n"(LANE));
-}
-
 __device__ inline uint32_t maj4(uint32_t a, uint32_t b, uint32_t c, uint32_t d) {
   // at least two of four set, bitwise (act(AvgPool2d(2)(x) - 0.5), :93-94)
   return (a & b) | (c & d) | ((a | b) & (c | d));
@@ -68,15 +57,6 @@ __device__ inline uint32_t row_field(uint32_t lo, uint32_t hi) {
   if constexpr (SH + KW <= 32) return (lo >> SH) & mask;
   else if constexpr (SH >= 32) return (hi >> (SH - 32)) & mask;
   else return __builtin_amdgcn_alignbit(hi, lo, SH) & mask;
-}
-
-// compile-time loop: f(integral_constant<int, I>) for I in [0, N)
-template <int I, int N, typename F>
-__device__ inline void static_for(F &&f) {
-  if constexpr (I < N) {
-    f(std::integral_constant<int, I>{});
-    static_for<I + 1, N>(f);
-  }
 }
 
 // One output row per lane, all WO columns: first every window index and its table read are

@@ -27,17 +27,29 @@ __global__ __launch_bounds__(256) void stem_kernel(const float *__restrict__ x, 
   __shared__ float tile[3][PR][PWS];
   const int n = blockIdx.y, oy0 = blockIdx.x * ROWS;
   const int H = 224, W = 224;
-  // pooled row r of the tile is pooled image row 2*oy0 - 3 + r
-  for (int i = threadIdx.x; i < 3 * PR * PW; i += blockDim.x) {
-    const int px = i % PW, r = (i / PW) % PR, c = i / (PW * PR);
-    const int iy = 2 * oy0 - 3 + r, ix = px - 3;
-    float v = 0.f;
-    if (iy >= 0 && iy < 112 && ix >= 0 && ix < 112) {
-      const float *src = x + (((size_t)n * 3 + c) * H + 2 * iy) * W + 2 * ix;
-      const float2 a = *(const float2 *)src, b = *(const float2 *)(src + W);
-      v = (((a.x + a.y) + b.x) + b.y) * 0.25f;
+  // pooled row r of the tile is pooled image row 2*oy0 - 3 + r; one wave per (c, r) row,
+  // lanes along the row (no integer division in the address math)
+  {
+    const int lane_ = threadIdx.x & 63, wave_ = threadIdx.x >> 6;
+    for (int cr = wave_; cr < 3 * PR; cr += 4) {
+      const int c = cr / PR, r = cr - c * PR;      // wave-uniform
+      const int iy = 2 * oy0 - 3 + r;
+      const bool row_ok = iy >= 0 && iy < 112;
+      const float *src_row = x + (((size_t)n * 3 + c) * H + 2 * (row_ok ? iy : 0)) * W;
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const int px = lane_ + 64 * k;
+        if (px < PW) {
+          const int ix = px - 3;
+          float v = 0.f;
+          if (row_ok && ix >= 0 && ix < 112) {
+            const float2 a = *(const float2 *)(src_row + 2 * ix), b = *(const float2 *)(src_row + W + 2 * ix);
+            v = (((a.x + a.y) + b.x) + b.y) * 0.25f;
+          }
+          tile[c][r][px] = v;
+        }
+      }
     }
-    tile[c][r][px] = v;
   }
   __syncthreads();
 
@@ -68,21 +80,23 @@ __global__ __launch_bounds__(256) void stem_kernel(const float *__restrict__ x, 
         }
       }
     }
-    uint64_t keep = 0;
-#pragma unroll
-    for (int r = 0; r < ROWS; ++r) {
+    // BN + sign; the ballot of a (row, channel) is its row word; lane r*16+j keeps it
+    uint32_t keep_lo = 0, keep_hi = 0;
+    const uint64_t live = (1ull << 56) - 1ull;
+    static_for<0, ROWS>([&](auto rr) {
+      constexpr int r = decltype(rr)::value;
       uint32_t word = 0;
-#pragma unroll
-      for (int j = 0; j < 16; ++j) {
+      static_for<0, 16>([&](auto jj) {
+        constexpr int j = decltype(jj)::value;
         const int ch = grp * 16 + j;
         const float pre = fmaf(acc[r][j], scale[ch], shift[ch]);
-        const bool bit = (lane < 56) && (pre >= 0.0f);
-        const uint64_t m = __ballot(bit);
-        if (lane == r * 16 + j) keep = m;
-        word |= (bit ? 1u : 0u) << j;
-      }
+        const uint64_t m = __ballot(pre >= 0.0f) & live;
+        writelane64<r * 16 + j>(keep_lo, keep_hi, m);
+        word |= (pre >= 0.0f) ? (1u << j) : 0u;
+      });
       if (lane < 56) cp[(((size_t)n * ngroups + grp) * 56 + oy0 + r) * 56 + lane] = (uint16_t)word;
-    }
+    });
+    const uint64_t keep = ((uint64_t)keep_hi << 32) | keep_lo;
     // lane L holds the row word of channel grp*16 + (L&15), output row oy0 + (L>>4)
     rp[((size_t)n * p + grp * 16 + (lane & 15)) * 56 + oy0 + (lane >> 4)] = keep;
   }

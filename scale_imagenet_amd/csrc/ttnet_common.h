@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "../../include/ttnet.h"
@@ -50,6 +51,28 @@ struct BlockGeom {
     return b < 4 ? 4 : b;
   }
 };
+
+#if defined(__HIPCC__)
+// Lane LANE of (lo,hi) := a wave-uniform 64-bit value (v_writelane_b32; hipcc exposes no
+// builtin).  gfx950 needs 2 wait states between a VALU write of an SGPR (the v_cmp of a
+// ballot) and a VALU read of it; hipcc pads that for its own instructions but not inside
+// an asm statement, hence the s_nop.
+template <int LANE>
+__device__ inline void writelane64(uint32_t &lo, uint32_t &hi, uint64_t sval) {
+  asm("s_nop 1\n\tv_writelane_b32 %0, %2, %4\n\tv_writelane_b32 %1, %3, %4"
+      : "+v"(lo), "+v"(hi)
+      : "s"((uint32_t)sval), "s"((uint32_t)(sval >> 32)), "n"(LANE));
+}
+
+// compile-time loop: f(integral_constant<int, I>) for I in [0, N)
+template <int I, int N, typename F>
+__device__ inline void static_for(F &&f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, N>(f);
+  }
+}
+#endif
 
 // ---- launchers (defined next to their kernels) ------------------------------------------
 
