@@ -96,7 +96,8 @@ struct ttnet_plan {
   bool finalized = false;
 
   // stem
-  float *stem_wt = nullptr, *stem_scale = nullptr, *stem_shift = nullptr;
+  uint16_t *stem_wt = nullptr;      // bf16 x 3 split weights, fragment order
+  float *stem_scale = nullptr, *stem_shift = nullptr;
   // activations: x_rp[i] / x_cp[i] = input of block i
   std::vector<uint64_t *> x_rp;
   std::vector<uint16_t *> x_cp;
@@ -198,8 +199,8 @@ int build_geometry(ttnet_plan *pl) {
   }
   const int p = d.nfilter * d.tfilter;
   pl->p = p;
-  if (p % 16) {
-    set_error("p = nfilter*tfilter = %d must be a multiple of 16", p);
+  if (p != 64) {
+    set_error("p = nfilter*tfilter = %d: this build has the p = 64 stem kernel only", p);
     return TTNET_E_UNSUPPORTED;
   }
   std::vector<int> cfg;
@@ -285,7 +286,7 @@ int allocate(ttnet_plan *pl) {
   const int nb = pl->desc.max_batch;
   size_t *ws = &pl->workspace_bytes, *tb = &pl->table_bytes;
   for (auto &kv : pl->tensors) TT_TRY(dev_alloc(pl, (uint8_t **)&kv.second.dev, kv.second.bytes, true));
-  TT_TRY(dev_alloc(pl, &pl->stem_wt, (size_t)147 * pl->p, false));
+  TT_TRY(dev_alloc(pl, &pl->stem_wt, stem_split_weights_elems(), false));
   TT_TRY(dev_alloc(pl, &pl->stem_scale, pl->p, false));
   TT_TRY(dev_alloc(pl, &pl->stem_shift, pl->p, false));
   pl->x_rp.resize(pl->blocks.size());
@@ -553,14 +554,13 @@ int ttnet_plan_finalize(ttnet_plan *pl, void *stream) {
       return TTNET_E_STATE;
     }
   }
-  // stem: weights to tap-major [147][p]; BN folded to fp32 scale/shift
+  // stem: weights split into three bf16 planes in MFMA fragment order; BN folded to fp32 scale/shift
   {
     std::vector<float> w;
     TT_TRY(fetch(pl->tensors["features.1.weight"], w));
-    std::vector<float> wt((size_t)147 * pl->p);
-    for (int ch = 0; ch < pl->p; ++ch)
-      for (int tap = 0; tap < 147; ++tap) wt[(size_t)tap * pl->p + ch] = w[(size_t)ch * 147 + tap];
-    TT_HIP(hipMemcpy(pl->stem_wt, wt.data(), wt.size() * 4, hipMemcpyHostToDevice));
+    std::vector<uint16_t> wf(stem_split_weights_elems());
+    stem_split_weights(w.data(), wf.data());
+    TT_HIP(hipMemcpy(pl->stem_wt, wf.data(), wf.size() * 2, hipMemcpyHostToDevice));
     std::vector<double> sc, sh;
     TT_TRY(fold_bn(pl, "features.2", sc, sh));
     TT_TRY(upload_f32(pl->stem_scale, sc));

@@ -2,13 +2,29 @@
 // (models/TT_general_imagenet_v2_small.py:168-169, :183-184; binarisation netbin.py:193),
 // emitting the packed bits in both layouts the gate path reads (include/ttnet.h).
 //
-// fp32 throughout: bf16 operands flip ~0.07 % of the stem bits, so the
-// contraction stays in exact fp32 FMA.  One workgroup = one image x ROWS output rows; the
-// pooled input tile lives in LDS; a wave owns 16 output channels and its 64 lanes own the
-// output columns, so the 16 weights of a tap are wave-uniform (scalar loads) and the
-// binarised outputs pack with one ballot (row layout) / one shift-or chain (channel layout).
+// Arithmetic.  The result must keep the reference's float32 meaning: plain bf16 operands
+// flip ~0.07 % of the stem bits.  The exact-f32 MFMA runs at 1/16 of the bf16
+// MFMA rate (and the f32 VALU, packed or not, at about half of that in practice), so the
+// contraction is done on the bf16 matrix cores with every f32 operand split into three bf16
+// terms (x = x1 + x2 + x3 exactly: 3 x 8 mantissa bits) and the six products of weight
+// >= 2^-16 kept:  w1x1 + w1x2 + w2x1 + w2x2 + w1x3 + w3x1, each an MFMA with exact
+// bf16 x bf16 products and f32 accumulation.  The dropped terms are <= 3 * 2^-24 relative
+// (7e-8 absolute on the pre-activation of the synthetic model, 70x below the f32 rounding
+// noise of the reference itself); the output bits are oracle-checked, exact except at near
+// ties.
 //
-// Bound: fp32 VALU/MFMA, 29.5 MMAC per image (157 TFLOP/s peak).
+// Shape.  Implicit GEMM  D[channel][pixel] = W[channel][k] * patch[k][pixel]  with
+// k = ((c*7 + kh)*8 + kw), kw padded 7 -> 8 with a zero weight so that one bf16x8 B-fragment
+// is 8 consecutive pooled pixels of one tile row.  v_mfma_f32_32x32x16_bf16: M = 32 channels,
+// N = 32 output pixels, K = 16 = two (c,kh) rows.  One workgroup = one image x 8 output rows
+// (448 pixels = 14 N-tiles over 4 waves); the pooled tile lives in LDS as three bf16 planes;
+// the weights are pre-split and pre-swizzled into fragment order at finalize and stream from
+// L2 (67 KB, shared by every workgroup).
+//
+// Bound: bf16 MFMA (2.5 PFLOP/s dense) at 6 MFMA flops per algorithmic flop (7 with the kw
+// padding); 29.5 MMAC/image.
+
+#include <string.h>
 
 #include "ttnet_common.h"
 
@@ -16,101 +32,259 @@ namespace ttnet {
 
 namespace {
 
-constexpr int ROWS = 4;                    // output rows per workgroup
-constexpr int PR = 2 * ROWS + 5;           // pooled rows needed
-constexpr int PW = 112 + 6;                // pooled row with 3 columns of zero padding each side
-constexpr int PWS = PW + 2;                // LDS row stride (keeps rows 8-byte aligned)
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-__global__ __launch_bounds__(256) void stem_kernel(const float *__restrict__ x, const float *__restrict__ wt,
-                                                  const float *__restrict__ scale, const float *__restrict__ shift,
-                                                  uint64_t *__restrict__ rp, uint16_t *__restrict__ cp, int p) {
-  __shared__ float tile[3][PR][PWS];
-  const int n = blockIdx.y, oy0 = blockIdx.x * ROWS;
+constexpr int SR = 8;                  // output rows per workgroup
+constexpr int TR = 2 * SR + 5;         // pooled rows in the tile
+constexpr int TW = 120;                // tile row pitch in elements (118 used)
+constexpr int KSTEPS = 11;             // 22 (c,kh) rows (21 + one zero row), two per MFMA
+constexpr int NT = SR * 56 / 32;       // 14 N-tiles of 32 pixels
+constexpr int TPW = 4;                 // N-tiles per wave (waves 2,3 own 3)
+constexpr int PLANE = 3 * TR * TW;     // elements per bf16 plane
+
+__device__ inline uint32_t bf16_rne(float x) {
+  uint32_t u = __float_as_uint(x);
+  u += 0x7FFFu + ((u >> 16) & 1u);
+  return u >> 16;
+}
+__device__ inline float bf16_f32(uint32_t b) { return __uint_as_float(b << 16); }
+
+__global__ __launch_bounds__(256, 2) void stem_mfma_kernel(const float *__restrict__ x, const uint4 *__restrict__ wfrag,
+                                                          const float *__restrict__ scale,
+                                                          const float *__restrict__ shift, uint64_t *__restrict__ rp,
+                                                          uint16_t *__restrict__ cp) {
+  __shared__ __align__(16) uint16_t tile[3 * PLANE];   // [plane][c][row][col] bf16
+  __shared__ float s_scale[64], s_shift[64];
+  __shared__ uint32_t stage[64][NT + 2];                // row-layout staging: bit = pixel within the block
+  const int n = blockIdx.y, oy0 = blockIdx.x * SR;
   const int H = 224, W = 224;
-  // pooled row r of the tile is pooled image row 2*oy0 - 3 + r; one wave per (c, r) row,
-  // lanes along the row (no integer division in the address math)
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (threadIdx.x < 64) {
+    s_scale[threadIdx.x] = scale[threadIdx.x];
+    s_shift[threadIdx.x] = shift[threadIdx.x];
+    stage[threadIdx.x][NT] = 0;
+    stage[threadIdx.x][NT + 1] = 0;
+  }
+  // pooled tile row r = pooled image row 2*oy0 - 3 + r.  A wave owns (c, r) rows wave, wave+4, ...
+  // and walks them in batches of B rows with every global load of the batch in flight before
+  // the first use (the tile build is otherwise a chain of dependent HBM round trips).
   {
-    const int lane_ = threadIdx.x & 63, wave_ = threadIdx.x >> 6;
-    for (int cr = wave_; cr < 3 * PR; cr += 4) {
-      const int c = cr / PR, r = cr - c * PR;      // wave-uniform
-      const int iy = 2 * oy0 - 3 + r;
-      const bool row_ok = iy >= 0 && iy < 112;
-      const float *src_row = x + (((size_t)n * 3 + c) * H + 2 * (row_ok ? iy : 0)) * W;
+    constexpr int B = 8, ROWS_PER_WAVE = (3 * TR + 3) / 4;      // 16
+    for (int b0 = 0; b0 < ROWS_PER_WAVE; b0 += B) {
+      float2 ra[B][2], rb[B][2];
 #pragma unroll
-      for (int k = 0; k < 2; ++k) {
-        const int px = lane_ + 64 * k;
-        if (px < PW) {
-          const int ix = px - 3;
-          float v = 0.f;
-          if (row_ok && ix >= 0 && ix < 112) {
-            const float2 a = *(const float2 *)(src_row + 2 * ix), b = *(const float2 *)(src_row + W + 2 * ix);
-            v = (((a.x + a.y) + b.x) + b.y) * 0.25f;
+      for (int bi = 0; bi < B; ++bi) {
+        const int cr = wave + 4 * (b0 + bi);
+        const int c = cr / TR, r = cr - c * TR;
+        const int iy = 2 * oy0 - 3 + r;
+        const bool row_ok = cr < 3 * TR && iy >= 0 && iy < 112;
+        const float *src_row = x + (((size_t)n * 3 + (row_ok ? c : 0)) * H + 2 * (row_ok ? iy : 0)) * W;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+          const int ix = lane + 64 * k - 3;
+          const bool ok = row_ok && ix >= 0 && ix < 112;
+          ra[bi][k] = ok ? *(const float2 *)(src_row + 2 * ix) : make_float2(0.f, 0.f);
+          rb[bi][k] = ok ? *(const float2 *)(src_row + W + 2 * ix) : make_float2(0.f, 0.f);
+        }
+      }
+#pragma unroll
+      for (int bi = 0; bi < B; ++bi) {
+        const int cr = wave + 4 * (b0 + bi);
+        if (cr < 3 * TR) {
+          const int c = cr / TR, r = cr - c * TR;
+#pragma unroll
+          for (int k = 0; k < 2; ++k) {
+            const int px = lane + 64 * k;
+            if (px < TW) {
+              const float v = (((ra[bi][k].x + ra[bi][k].y) + rb[bi][k].x) + rb[bi][k].y) * 0.25f;
+              const uint32_t b1 = bf16_rne(v);
+              const float r1 = v - bf16_f32(b1);
+              const uint32_t b2 = bf16_rne(r1);
+              const uint32_t b3 = bf16_rne(r1 - bf16_f32(b2));
+              const int e = (c * TR + r) * TW + px;
+              tile[e] = (uint16_t)b1;
+              tile[PLANE + e] = (uint16_t)b2;
+              tile[2 * PLANE + e] = (uint16_t)b3;
+            }
           }
-          tile[c][r][px] = v;
         }
       }
     }
   }
   __syncthreads();
 
-  const int lane = threadIdx.x & 63;
-  const int cg = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // 16-channel group of this wave
-  const int ox = lane < 56 ? lane : 55;
-  const int ngroups = p / 16;
-  for (int grp = cg; grp < ngroups; grp += 4) {
-    float acc[ROWS][16];
+  const int h = lane >> 5, col = lane & 31;
+  // element offset (within a plane) of this lane's pixel in each of the wave's N-tiles
+  int pixoff[TPW];
 #pragma unroll
-    for (int r = 0; r < ROWS; ++r)
+  for (int i = 0; i < TPW; ++i) {
+    const int t = wave + 4 * i;
+    const int p = 32 * (t < NT ? t : 0) + col;
+    const int oyl = p / 56, ox = p - 56 * oyl;
+    pixoff[i] = 2 * oyl * TW + 2 * ox;
+  }
+  f32x16 acc[TPW][2];
 #pragma unroll
-      for (int j = 0; j < 16; ++j) acc[r][j] = 0.f;
-    for (int c = 0; c < 3; ++c) {
-      for (int kh = 0; kh < 7; ++kh) {
+  for (int i = 0; i < TPW; ++i)
 #pragma unroll
-        for (int kw = 0; kw < 7; ++kw) {
-          const float *wp = wt + (size_t)((c * 7 + kh) * 7 + kw) * p + grp * 16;   // wave-uniform
-          float v[ROWS];
+    for (int m = 0; m < 2; ++m)
 #pragma unroll
-          for (int r = 0; r < ROWS; ++r) v[r] = tile[c][2 * r + kh][2 * ox + kw];
+      for (int r = 0; r < 16; ++r) acc[i][m][r] = 0.f;
+
+  const uint32_t *tile32 = (const uint32_t *)tile;
+  // weights in fragment order [ks][plane][mtile][lane] x 16 bytes: 1 KiB per wave load, fetched
+  // one k-step ahead (L2 latency would otherwise be exposed 11 times)
+  uint4 aw_next[3][2];
 #pragma unroll
-          for (int j = 0; j < 16; ++j) {
-            const float w = wp[j];
+  for (int pl = 0; pl < 3; ++pl)
 #pragma unroll
-            for (int r = 0; r < ROWS; ++r) acc[r][j] = fmaf(v[r], w, acc[r][j]);
-          }
+    for (int m = 0; m < 2; ++m) aw_next[pl][m] = wfrag[(pl * 2 + m) * 64 + lane];
+  for (int ks = 0; ks < KSTEPS; ++ks) {
+    uint4 aw[3][2];
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+      for (int m = 0; m < 2; ++m) aw[pl][m] = aw_next[pl][m];
+    if (ks + 1 < KSTEPS) {
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+        for (int m = 0; m < 2; ++m) aw_next[pl][m] = wfrag[(((ks + 1) * 3 + pl) * 2 + m) * 64 + lane];
+    }
+    int R = 2 * ks + h;                    // (c,kh) row of this half-wave's 8 k values
+    if (R > 20) R = 20;                    // zero-weight pad row: any finite data
+    const int c = (R * 37) >> 8, kh = R - 7 * c;
+    const int rowoff = (c * TR + kh) * TW;
+#pragma unroll
+    for (int i = 0; i < TPW; ++i) {
+      if (wave + 4 * i < NT) {             // wave-uniform
+        const int e = (rowoff + pixoff[i]) >> 1;       // dword index: both terms are even
+        bf16x8 bx[3];
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) {
+          uint4 v;
+          v.x = tile32[pl * (PLANE / 2) + e];
+          v.y = tile32[pl * (PLANE / 2) + e + 1];
+          v.z = tile32[pl * (PLANE / 2) + e + 2];
+          v.w = tile32[pl * (PLANE / 2) + e + 3];
+          bx[pl] = __builtin_bit_cast(bf16x8, v);
+        }
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+          const bf16x8 w1 = __builtin_bit_cast(bf16x8, aw[0][m]), w2 = __builtin_bit_cast(bf16x8, aw[1][m]),
+                       w3 = __builtin_bit_cast(bf16x8, aw[2][m]);
+          f32x16 a = acc[i][m];
+          a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w3, bx[0], a, 0, 0, 0);
+          a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, bx[2], a, 0, 0, 0);
+          a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w2, bx[1], a, 0, 0, 0);
+          a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w2, bx[0], a, 0, 0, 0);
+          a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, bx[1], a, 0, 0, 0);
+          a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, bx[0], a, 0, 0, 0);
+          acc[i][m] = a;
         }
       }
     }
-    // BN + sign; the ballot of a (row, channel) is its row word; lane r*16+j keeps it
-    uint32_t keep_lo = 0, keep_hi = 0;
-    const uint64_t live = (1ull << 56) - 1ull;
-    static_for<0, ROWS>([&](auto rr) {
-      constexpr int r = decltype(rr)::value;
-      uint32_t word = 0;
-      static_for<0, 16>([&](auto jj) {
-        constexpr int j = decltype(jj)::value;
-        const int ch = grp * 16 + j;
-        const float pre = fmaf(acc[r][j], scale[ch], shift[ch]);
-        const uint64_t m = __ballot(pre >= 0.0f) & live;
-        writelane64<r * 16 + j>(keep_lo, keep_hi, m);
-        word |= (pre >= 0.0f) ? (1u << j) : 0u;
+  }
+
+  // epilogue: BN + sign.  C/D layout of the 32x32 MFMA: column = lane&31 (pixel),
+  // row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) (channel within the M-tile).
+  float bsc[2][16], bsh[2][16];
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int ch = m * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+      bsc[m][r] = s_scale[ch];
+      bsh[m][r] = s_shift[ch];
+    }
+#pragma unroll
+  for (int i = 0; i < TPW; ++i) {
+    const int t = wave + 4 * i;
+    if (t >= NT) continue;
+    const int p = 32 * t + col;
+    const int oyl = p / 56, ox = p - 56 * oyl;
+    uint32_t klo = 0, khi = 0;             // lane 16m + r keeps the ballot of (m, r)
+    static_for<0, 2>([&](auto mm) {
+      constexpr int m = decltype(mm)::value;
+      uint32_t pw0 = 0, pw1 = 0;
+      static_for<0, 16>([&](auto rr) {
+        constexpr int r = decltype(rr)::value;
+        const float pre = fmaf(acc[i][m][r], bsc[m][r], bsh[m][r]);
+        const bool bit = pre >= 0.0f;
+        writelane64<16 * m + r>(klo, khi, __ballot(bit));
+        constexpr uint32_t kbit = (r & 3) + 8 * ((r >> 2) & 1);
+        if constexpr (r < 8) pw0 |= bit ? (1u << kbit) : 0u;
+        else pw1 |= bit ? (1u << kbit) : 0u;
       });
-      if (lane < 56) cp[(((size_t)n * ngroups + grp) * 56 + oy0 + r) * 56 + lane] = (uint16_t)word;
+      uint32_t pw = (pw0 | (pw1 << 16)) << (4 * h);
+      pw |= (uint32_t)__shfl_xor((int)pw, 32);
+      // half-wave 0 stores group 2m, half-wave 1 group 2m+1
+      const int q = 2 * m + h;
+      cp[(((size_t)n * 4 + q) * 56 + oy0 + oyl) * 56 + ox] = (uint16_t)(h ? (pw >> 16) : pw);
     });
-    const uint64_t keep = ((uint64_t)keep_hi << 32) | keep_lo;
-    // lane L holds the row word of channel grp*16 + (L&15), output row oy0 + (L>>4)
-    rp[((size_t)n * p + grp * 16 + (lane & 15)) * 56 + oy0 + (lane >> 4)] = keep;
+    if (lane < 32) {                        // lanes 0-31 of the ballot: channel chl, lanes 32-63: chl + 4
+      const int m = lane >> 4, r = lane & 15;
+      const int chl = m * 32 + (r & 3) + 8 * (r >> 2);
+      stage[chl][t] = klo;
+      stage[chl + 4][t] = khi;
+    }
+  }
+  __syncthreads();
+  for (int idx = threadIdx.x; idx < 64 * SR; idx += blockDim.x) {
+    const int ch = idx & 63, row = idx >> 6;
+    const int b0 = 56 * row, w0 = b0 >> 5, s = b0 & 31;
+    const uint64_t lo = stage[ch][w0] | ((uint64_t)stage[ch][w0 + 1] << 32);
+    const uint64_t hi = stage[ch][w0 + 2];
+    uint64_t v = lo >> s;
+    if (s) v |= hi << (64 - s);
+    rp[((size_t)n * 64 + ch) * 56 + oy0 + row] = v & ((1ull << 56) - 1ull);
   }
 }
 
 }  // namespace
 
-int launch_stem(const float *x, const float *wt, const float *scale, const float *shift, uint64_t *rp,
+// Host side of the operand split: w [64][3][7][7] float32 -> fragment-ordered bf16 planes
+// [ks][plane][mtile][lane][8]: lane l of M-tile m holds channel 32m + (l&31), k = 16ks + 8(l>>5) + j,
+// k = ((c*7 + kh)*8 + kw); kw = 7 and the 22nd (c,kh) row carry zero weights.
+void stem_split_weights(const float *w, uint16_t *out) {
+  auto rne = [](float x) {
+    uint32_t u;
+    memcpy(&u, &x, 4);
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+  };
+  auto tof = [](uint16_t b) {
+    uint32_t u = (uint32_t)b << 16;
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+  };
+  for (int ks = 0; ks < KSTEPS; ++ks)
+    for (int m = 0; m < 2; ++m)
+      for (int l = 0; l < 64; ++l)
+        for (int j = 0; j < 8; ++j) {
+          const int ch = 32 * m + (l & 31), R = 2 * ks + (l >> 5), kw = j;
+          float v = 0.f;
+          if (R < 21 && kw < 7) v = w[(size_t)ch * 147 + R * 7 + kw];     // R = c*7 + kh
+          const uint16_t b1 = rne(v);
+          const float r1 = v - tof(b1);
+          const uint16_t b2 = rne(r1);
+          const uint16_t b3 = rne(r1 - tof(b2));
+          const uint16_t parts[3] = {b1, b2, b3};
+          for (int pl = 0; pl < 3; ++pl) out[((((size_t)ks * 3 + pl) * 2 + m) * 64 + l) * 8 + j] = parts[pl];
+        }
+}
+
+size_t stem_split_weights_elems() { return (size_t)KSTEPS * 3 * 2 * 64 * 8; }
+
+int launch_stem(const float *x, const void *wfrag, const float *scale, const float *shift, uint64_t *rp,
                 uint16_t *cp, int n, int p, hipStream_t s) {
-  if (p % 16) {
-    set_error("stem: p=%d must be a multiple of 16", p);
+  if (p != 64) {
+    set_error("stem: this build has the p = 64 kernel only (p=%d)", p);
     return TTNET_E_UNSUPPORTED;
   }
-  hipLaunchKernelGGL(stem_kernel, dim3(56 / ROWS, n), dim3(256), 0, s, x, wt, scale, shift, rp, cp, p);
+  hipLaunchKernelGGL(stem_mfma_kernel, dim3(56 / SR, n), dim3(256), 0, s, x, (const uint4 *)wfrag, scale, shift, rp, cp);
   TT_HIP(hipGetLastError());
   return TTNET_OK;
 }

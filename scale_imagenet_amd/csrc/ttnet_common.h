@@ -90,8 +90,11 @@ struct LutBuildArgs {
 int launch_lut_build(const LutBuildArgs &a, hipStream_t s);
 
 // stem.hip
-int launch_stem(const float *x, const float *wt, const float *scale, const float *shift, uint64_t *rp,
+// wfrag: the conv weights split into three bf16 planes in MFMA fragment order (stem_split_weights)
+int launch_stem(const float *x, const void *wfrag, const float *scale, const float *shift, uint64_t *rp,
                 uint16_t *cp, int n, int p, hipStream_t s);
+void stem_split_weights(const float *w /*[64][3][7][7]*/, uint16_t *out);
+size_t stem_split_weights_elems();
 
 // gate.hip
 struct GateBlockArgs {
