@@ -355,7 +355,7 @@ __global__ __launch_bounds__(kGateThreads) void gate_pf_kernel(GateBlockArgs a, 
 // row; the table for all 64 groups is 256 MiB and sits in HBM / Infinity Cache.  The
 // following AvgPool2d(2) (:197) is fused: four rows are gathered and averaged.
 // 16 lanes share one (image, group, pooled pixel) and read one 64-byte row together.
-__global__ __launch_bounds__(256) void gate_last_kernel(GateBlockArgs a, const float *t_last, float *feat) {
+__global__ __launch_bounds__(256) void gate_last_kernel(GateBlockArgs a, const float *t_last, uint16_t *feat_frag) {
   const int Q = a.C / 16, G = a.C / 4;
   const int Hp = a.Ho / 2, Wp = a.Wo / 2, PP = Hp * Wp;
   const size_t task = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
@@ -374,7 +374,25 @@ __global__ __launch_bounds__(256) void gate_last_kernel(GateBlockArgs a, const f
                          (((a.o3[pix] >> sh) & 15) << 8) | (((a.o4[pix] >> sh) & 15) << 12);
     v[d] = tab[(size_t)idx * 16 + k];
   }
-  feat[task * 16 + k] = (((v[0] + v[1]) + v[2]) + v[3]) * 0.25f;
+  const float f = (((v[0] + v[1]) + v[2]) + v[3]) * 0.25f;
+  // exact 3-way bf16 split, stored where lin1's MFMA fragments expect it:
+  // row = image, k-step = g*PP + pp, lane = (n&31) + 32*(k>>3), element k&7
+  uint32_t u = __float_as_uint(f);
+  u += 0x7FFFu + ((u >> 16) & 1u);
+  const uint32_t b1 = u >> 16;
+  const float r1 = f - __uint_as_float(b1 << 16);
+  u = __float_as_uint(r1);
+  u += 0x7FFFu + ((u >> 16) & 1u);
+  const uint32_t b2 = u >> 16;
+  const float r2 = r1 - __uint_as_float(b2 << 16);
+  u = __float_as_uint(r2);
+  u += 0x7FFFu + ((u >> 16) & 1u);
+  const uint32_t b3 = u >> 16;
+  const int KS = G * PP, ks = g * PP + pp, ln = (n & 31) + 32 * (k >> 3), j = k & 7;
+  const size_t base = ((size_t)(n >> 5) * KS + ks) * 3;
+  feat_frag[((base + 0) * 64 + ln) * 8 + j] = (uint16_t)b1;
+  feat_frag[((base + 1) * 64 + ln) * 8 + j] = (uint16_t)b2;
+  feat_frag[((base + 2) * 64 + ln) * 8 + j] = (uint16_t)b3;
 }
 
 // ---- layout conversions (parity taps and ttnet_forward_from_stem_bits only) -----------------
@@ -409,15 +427,6 @@ __global__ void rp_to_cp_kernel(const uint64_t *rp, uint16_t *cp, int n, int C, 
     for (int k = 0; k < 16; ++k) w |= (uint32_t)((rows[k] >> x) & 1ull) << k;
     cp[(((size_t)img * Q + q) * H + y) * W + x] = (uint16_t)w;
   }
-}
-
-__global__ void feat_to_ref_kernel(const float *feat, float *out, int n, int G, int PP) {
-  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const size_t per = (size_t)G * PP * 16;
-  if (t >= (size_t)n * per) return;
-  const int k = t % 16, pp = (t / 16) % PP, g = (t / (16 * (size_t)PP)) % G;
-  const size_t img = t / per;
-  out[img * per + ((size_t)(16 * g + k)) * PP + pp] = feat[t];
 }
 
 // images per slice so that `units` table sets spread over about `target` workgroups
@@ -484,10 +493,10 @@ int launch_gate_pf(const GateBlockArgs &a, const uint8_t *t_cf, uint16_t *out_cp
   return TTNET_E_UNSUPPORTED;
 }
 
-int launch_gate_last(const GateBlockArgs &a, const float *t_last, float *feat, hipStream_t s) {
+int launch_gate_last(const GateBlockArgs &a, const float *t_last, void *feat_frag, hipStream_t s) {
   const size_t tasks = (size_t)a.n * (a.C / 4) * (a.Ho / 2) * (a.Wo / 2);
   const size_t threads = tasks * 16;
-  hipLaunchKernelGGL(gate_last_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, a, t_last, feat);
+  hipLaunchKernelGGL(gate_last_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, a, t_last, (uint16_t *)feat_frag);
   TT_HIP(hipGetLastError());
   return TTNET_OK;
 }
@@ -502,13 +511,6 @@ int launch_cp_to_rp(const uint16_t *cp, uint64_t *rp, int n, int C, int H, int W
 int launch_rp_to_cp(const uint64_t *rp, uint16_t *cp, int n, int C, int H, int W, hipStream_t s) {
   const size_t t = (size_t)n * (C / 16) * H;
   hipLaunchKernelGGL(rp_to_cp_kernel, dim3((unsigned)((t + 127) / 128)), dim3(128), 0, s, rp, cp, n, C, H, W);
-  TT_HIP(hipGetLastError());
-  return TTNET_OK;
-}
-
-int launch_feat_to_reference_order(const float *feat, float *out, int n, int G, int PP, hipStream_t s) {
-  const size_t t = (size_t)n * G * PP * 16;
-  hipLaunchKernelGGL(feat_to_ref_kernel, dim3((unsigned)((t + 255) / 256)), dim3(256), 0, s, feat, out, n, G, PP);
   TT_HIP(hipGetLastError());
   return TTNET_OK;
 }

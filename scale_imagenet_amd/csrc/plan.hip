@@ -101,9 +101,11 @@ struct ttnet_plan {
   // activations: x_rp[i] / x_cp[i] = input of block i
   std::vector<uint64_t *> x_rp;
   std::vector<uint16_t *> x_cp;
-  float *feat = nullptr;
+  uint16_t *feat = nullptr;         // features as 3 bf16 planes in lin1 fragment order
   // head
-  float *w1p = nullptr, *bn_scale = nullptr, *bn_shift = nullptr, *part = nullptr, *mid = nullptr;
+  float *w1p = nullptr;             // scratch for the permuted lin1 weights (finalize only)
+  uint16_t *w1f = nullptr;          // lin1 weights, 3 bf16 planes in fragment order
+  float *bn_scale = nullptr, *bn_shift = nullptr, *part = nullptr, *mid = nullptr;
   size_t part_elems = 0;
   size_t table_bytes = 0, workspace_bytes = 0;
   int64_t last_n = 0;
@@ -309,14 +311,16 @@ int allocate(ttnet_plan *pl) {
       TT_TRY(dev_alloc(pl, &b->near_dev, 1, true));
     }
   }
-  TT_TRY(dev_alloc(pl, &pl->feat, (size_t)nb * pl->fcsize, true, ws));
+  const int nb_pad = (nb + 255) / 256 * 256;          // the lin1 GEMM walks whole 256-row tiles
+  TT_TRY(dev_alloc(pl, &pl->feat, frag_elems(nb_pad, pl->fcsize), true, ws));
   TT_TRY(dev_alloc(pl, &pl->w1p, (size_t)pl->inter * pl->fcsize, false));
+  TT_TRY(dev_alloc(pl, &pl->w1f, frag_elems((pl->inter + 127) / 128 * 128, pl->fcsize), false));
   TT_TRY(dev_alloc(pl, &pl->bn_scale, pl->inter, false));
   TT_TRY(dev_alloc(pl, &pl->bn_shift, pl->inter, false));
   TT_TRY(dev_alloc(pl, &pl->mid, (size_t)nb * pl->inter, true, ws));
   size_t pe = 0;
   for (int n = 1; n <= nb; ++n) {
-    pe = std::max(pe, (size_t)gemm_splits(n, pl->inter, pl->fcsize) * n * pl->inter);
+    pe = std::max(pe, (size_t)gemm_bf16x3_splits(n, pl->inter, pl->fcsize / 16) * n * pl->inter);
     pe = std::max(pe, (size_t)gemm_splits(n, pl->n_classes, pl->inter) * n * pl->n_classes);
   }
   pl->part_elems = pe;
@@ -426,8 +430,8 @@ int run_from_blocks(ttnet_plan *pl, int n, float *logits, hipStream_t s) {
       TT_TIMED(pl, "gate_last", s, launch_gate_last(a, (const float *)mh.cf.table, pl->feat, s));
     }
   }
-  const int s1 = gemm_splits(n, pl->inter, pl->fcsize);
-  TT_TIMED(pl, "head.lin1", s, launch_gemm_nt_splitk(pl->feat, pl->w1p, pl->part, n, pl->inter, pl->fcsize, s1, s));
+  const int s1 = gemm_bf16x3_splits(n, pl->inter, pl->fcsize / 16);
+  TT_TIMED(pl, "head.lin1", s, launch_gemm_bf16x3(pl->feat, pl->w1f, pl->part, n, pl->inter, pl->fcsize, s1, s));
   TT_TIMED(pl, "head.bn_poly", s, launch_head_mid(pl->part, s1, pl->bn_scale, pl->bn_shift, pl->mid, n, pl->inter, s));
   const int s2 = gemm_splits(n, pl->n_classes, pl->inter);
   TT_TIMED(pl, "head.lin2", s,
@@ -575,6 +579,7 @@ int ttnet_plan_finalize(ttnet_plan *pl, void *stream) {
     TT_TRY(upload_f32(pl->bn_shift, sh));
     TT_TRY(launch_permute_lin1((const float *)pl->tensors[pl->head + ".lin1.weight"].dev, pl->w1p, pl->inter,
                                pl->featC / 16, pl->featPP, s));
+    TT_TRY(launch_split_to_frag(pl->w1p, pl->w1f, pl->inter, pl->fcsize, (pl->inter + 127) / 128 * 128, s));
   }
   TT_HIP(hipStreamSynchronize(s));
   for (auto &mh : pl->blocks)
@@ -650,7 +655,7 @@ int ttnet_read_stage(ttnet_plan *pl, const char *stage, int64_t n, void *dst, si
     float *tmp = nullptr;
     const size_t elems = (size_t)n * pl->fcsize;
     TT_HIP(hipMalloc((void **)&tmp, elems * 4));
-    int r = launch_feat_to_reference_order(pl->feat, tmp, (int)n, pl->featC / 16, pl->featPP, s);
+    int r = launch_frag_to_reference_order(pl->feat, tmp, (int)n, pl->featC / 16, pl->featPP, s);
     if (r == TTNET_OK) r = copy_out(tmp, elems * 4);
     (void)hipFree(tmp);
     return r;

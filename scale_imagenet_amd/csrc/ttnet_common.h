@@ -114,12 +114,18 @@ int launch_gate_stage1(const GateBlockArgs &a, hipStream_t s);
 // stage 2: convf of a non-last block: 4 branch tensors -> words [n][Cout/16][Ho][Wo] and rows
 // [n][Cout][Ho], Cout = 8 * (4C/16)
 int launch_gate_pf(const GateBlockArgs &a, const uint8_t *t_cf, uint16_t *out_cp, uint64_t *out_rp, hipStream_t s);
-// convf of the last block through the float table: -> feat [n][4C/16][pooled][16]
-int launch_gate_last(const GateBlockArgs &a, const float *t_last, float *feat, hipStream_t s);
+// convf of the last block through the float table, AvgPool2d(2) fused; the features are
+// written pre-split for lin1: fragment-ordered bf16 planes [n/32][(g*PP+pp)][3][64][8]
+int launch_gate_last(const GateBlockArgs &a, const float *t_last, void *feat_frag, hipStream_t s);
 int launch_cp_to_rp(const uint16_t *cp, uint64_t *rp, int n, int C, int H, int W, hipStream_t s);
 int launch_rp_to_cp(const uint64_t *rp, uint16_t *cp, int n, int C, int H, int W, hipStream_t s);
-// feat [n][G][PP][16] (device order) -> [n][(16g+k)*PP + pp] (reference Flatten order)
-int launch_feat_to_reference_order(const float *feat, float *out, int n, int G, int PP, hipStream_t s);
+// feature planes (fragment order) -> float32 [n][(16g+k)*PP + pp] (reference Flatten order)
+int launch_frag_to_reference_order(const void *af, float *out, int n, int G, int PP, hipStream_t s);
+// bf16 x 3 split GEMM on fragment-ordered operands: part[splits][M][N]
+int gemm_bf16x3_splits(int M, int N, int KS);
+int launch_gemm_bf16x3(const void *Af, const void *Bf, float *part, int M, int N, int K, int splits, hipStream_t s);
+size_t frag_elems(int rows, int K);
+int launch_split_to_frag(const float *src, void *dst, int R, int K, int rows_padded, hipStream_t s);
 
 // head.hip
 // C[M][N] (+)= A[M][K] * B[N][K]^T as split-K slabs: part[S][M][N]
