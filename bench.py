@@ -53,7 +53,7 @@ def kernel_models(batch: int):
     bytes of that launch + its tables once (the unfused per-layer accounting of SURVEY 8(d))."""
     m = {
         "stem": ("mfma_bf16x3", 2.0 * STEM_MAC * batch),
-        "head.lin1": ("mfma", 2.0 * LIN1_MAC * batch),
+        "head.lin1": ("mfma_bf16x3", 2.0 * LIN1_MAC * batch),
         "head.lin2": ("mfma", 2.0 * LIN2_MAC * batch),
         "head.bn_poly": ("hbm", 8.0 * 1000 * batch),
         "head.bias": ("hbm", 8.0 * 1000 * batch),
@@ -73,6 +73,20 @@ def kernel_models(batch: int):
             m["gate_last"] = ("hbm", batch * (4 * plane_out + (c // 4) * ho * ho * 64 + 4 * c * 16 * 4))
         c, h = 2 * c, ho
     return m
+
+
+def measured_traffic(batch: int):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/*traffic_b<B>.json,
+    collected with separate --pmc FETCH_SIZE / --pmc WRITE_SIZE runs of this script and corrected
+    as MI355X_MICROARCH.md prescribes).  bench.py cannot run the profiler on itself, so this is
+    the last committed measurement for this batch size, or nothing."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"*traffic_b{batch}.json")))
+    if not files:
+        return {}, None
+    with open(files[-1]) as f:
+        d = json.load(f)
+    return {k: v["hbm_bytes"] for k, v in d.get("kernels", {}).items()}, os.path.basename(files[-1])
 
 
 def host_cores() -> int:
@@ -173,6 +187,7 @@ def main():
 
     if rank == 0:
         models = kernel_models(B)
+        traffic, traffic_src = measured_traffic(B)
         kernels = []
         for k, ms in avg_ms.items():
             bound, units = models.get(k, ("hbm", 0.0))
@@ -185,7 +200,7 @@ def main():
             else:
                 ach, peak, unit = units / (ms * 1e-3) / 1e9, HBM_PEAK_GBS, "GB/s"
             kernels.append({"kernel": k, "ms": round(ms, 5), "bound": bound, "achieved": round(ach, 3),
-                            "peak": peak, "unit": unit, "frac": round(ach / peak, 5), "traffic": None})
+                            "peak": peak, "unit": unit, "frac": round(ach / peak, 5), "traffic": traffic.get(k)})
         gate_ms = sum(ms for k, ms in avg_ms.items() if k.startswith(("gate_stage1", "gate_pf")))
         gate_bytes = GATE_BYTES_PER_IMAGE * B + GATE_TABLE_BYTES
         gate = {"kernel": "gate_path (all binarised LUT launches)", "ms": round(gate_ms, 5), "bound": "hbm",
@@ -210,6 +225,7 @@ def main():
                        "parallelism": f"batch shard x{world}" + (" + RCCL all-gather of logits" if world > 1 else "")},
             "roofline": roofline,
             "roofline_kernels": kernels + [gate],
+            "traffic_source": traffic_src,
             "kernel_ms_sum": round(sum(avg_ms.values()), 5),
         }
         if world == 1 and not args.no_cpu_baseline:
