@@ -94,6 +94,7 @@ struct ttnet_plan {
   std::map<std::string, Tensor> tensors;
   std::vector<std::string> key_order;
   bool finalized = false;
+  bool xs = false;                  // x-small variant: row-packed branch tensors, gate_xs.hip kernels
 
   // stem
   uint16_t *stem_wt = nullptr;      // bf16 x 3 split weights, fragment order
@@ -181,8 +182,7 @@ int build_geometry(ttnet_plan *pl) {
   if (d.variant == TTNET_SMALL) {
   } else if (d.variant == TTNET_XSMALL) {
     kh = kw = 2; pad = 1; gsize = 4;
-    set_error("variant xsmall (fan-in 4) has no gate kernels in this build yet");
-    return TTNET_E_UNSUPPORTED;
+    pl->xs = true;
   } else if (d.variant == TTNET_FULL) {
     set_error("variant full (fan-in 30) cannot be a flat truth table (2^30 entries per output bit); "
               "its direct-arithmetic kernels are not built yet");
@@ -257,9 +257,12 @@ int build_geometry(ttnet_plan *pl) {
       b->perm.resize(b->g.nbits());
       for (int q = 0; q < b->g.nbits(); ++q) b->perm[q] = (uint8_t)q;
     }
-    mh.cf.perm.resize(16);
+    // convf group = gsize/4 channels x 4 branches; reference interleave is channel 4c+branch (:144-147),
+    // internal index bit = (gsize/4)*branch + channel-in-group
+    const int nch = gsize / 4;
+    mh.cf.perm.resize(gsize);
     for (int br = 0; br < 4; ++br)
-      for (int cl = 0; cl < 4; ++cl) mh.cf.perm[4 * br + cl] = (uint8_t)(4 * cl + br);   // channel 4c+branch
+      for (int cl = 0; cl < nch; ++cl) mh.cf.perm[nch * br + cl] = (uint8_t)(4 * cl + br);
     pl->blocks.push_back(mh);
     h = ho; w = wo;
     in_planes = 2 * out_planes;
@@ -297,8 +300,10 @@ int allocate(ttnet_plan *pl) {
     MultiHead &mh = pl->blocks[i];
     TT_TRY(dev_alloc(pl, &pl->x_rp[i], (size_t)nb * mh.C * mh.H, true, ws));
     TT_TRY(dev_alloc(pl, &pl->x_cp[i], (size_t)nb * mh.H * mh.W * (mh.C / 16), true, ws));
-    for (int b = 0; b < 4; ++b)   // zeroed once: the branch-padding border is never written again
-      TT_TRY(dev_alloc(pl, &mh.o[b], (size_t)nb * mh.Ho * mh.Wo * (mh.C / 16), true, ws));
+    for (int b = 0; b < 4; ++b) {  // zeroed once: the branch-padding border is never written again
+      const size_t words16 = (size_t)nb * mh.Ho * mh.Wo * (mh.C / 16), rows64 = (size_t)nb * mh.C * mh.Ho;
+      TT_TRY(dev_alloc(pl, &mh.o[b], pl->xs ? rows64 * 4 : words16, true, ws));
+    }
     for (BlockTT *b : {&mh.c1, &mh.c2, &mh.c3, &mh.cf}) {
       const BlockGeom &g = b->g;
       TT_TRY(dev_alloc(pl, (uint8_t **)&b->table, g.table_bytes(), true, tb));
@@ -422,6 +427,17 @@ int run_from_blocks(ttnet_plan *pl, int n, float *logits, hipStream_t s) {
   for (size_t i = 0; i < pl->blocks.size(); ++i) {
     MultiHead &mh = pl->blocks[i];
     GateBlockArgs a = gate_args(pl, i, n);
+    if (pl->xs) {
+      uint64_t *const o64[4] = {(uint64_t *)mh.o[0], (uint64_t *)mh.o[1], (uint64_t *)mh.o[2], (uint64_t *)mh.o[3]};
+      TT_TIMED(pl, kS1Names[i], s, launch_xs_branches(a, mh.c3.table, o64, s));
+      if (!mh.last)
+        TT_TIMED(pl, kPfNames[i], s,
+                 launch_xs_pf(n, mh.C, mh.Ho, mh.Wo, mh.cf.g.cout_g(), o64, mh.cf.table, pl->x_rp[i + 1], s));
+      else
+        TT_TIMED(pl, "gate_last", s,
+                 launch_xs_last(n, mh.C, mh.Ho, mh.Wo, mh.cf.g.cout_g(), o64, (const float *)mh.cf.table, pl->feat, s));
+      continue;
+    }
     TT_TIMED(pl, kS1Names[i], s, launch_gate_stage1(a, s));
     if (!mh.last) {
       TT_TIMED(pl, kPfNames[i], s,
@@ -641,8 +657,9 @@ int ttnet_read_stage(ttnet_plan *pl, const char *stage, int64_t n, void *dst, si
     if (st == in_name) return copy_out(pl->x_rp[i], (size_t)n * mh.C * mh.H * 8);
     for (int b = 0; b < 4; ++b) {
       if (st == mh.name + ".out" + std::to_string(b + 1)) {
-        uint64_t *tmp = nullptr;
         const size_t words = (size_t)n * mh.C * mh.Ho;
+        if (pl->xs) return copy_out(mh.o[b], words * 8);
+        uint64_t *tmp = nullptr;
         TT_HIP(hipMalloc((void **)&tmp, words * 8));
         int r = launch_cp_to_rp(mh.o[b], tmp, (int)n, mh.C, mh.Ho, mh.Wo, s);
         if (r == TTNET_OK) r = copy_out(tmp, words * 8);

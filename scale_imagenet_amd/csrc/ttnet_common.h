@@ -47,8 +47,11 @@ struct BlockGeom {
   size_t table_bytes() const {
     size_t entries = (size_t)groups << nbits();
     if (last) return entries * cout_g() * sizeof(float);
-    size_t b = entries * entry_bits() / 8;
-    return b < 4 ? 4 : b;
+    if (entry_bits() == 1) {                       // one dword minimum per group (16-entry tables)
+      const size_t per = ((size_t)1 << nbits()) / 8;
+      return (size_t)groups * (per < 4 ? 4 : per);
+    }
+    return entries * entry_bits() / 8;
   }
 };
 
@@ -117,6 +120,12 @@ int launch_gate_pf(const GateBlockArgs &a, const uint8_t *t_cf, uint16_t *out_cp
 // convf of the last block through the float table, AvgPool2d(2) fused; the features are
 // written pre-split for lin1: fragment-ordered bf16 planes [n/32][(g*PP+pp)][3][64][8]
 int launch_gate_last(const GateBlockArgs &a, const float *t_last, void *feat_frag, hipStream_t s);
+// x-small variant (fan-in 4, gate_xs.hip): everything on row-packed planes
+int launch_xs_branches(const GateBlockArgs &a, const void *t_c3, uint64_t *const o[4], hipStream_t s);
+int launch_xs_pf(int n, int C, int Ho, int Wo, int cout_g, uint64_t *const o[4], const void *t_cf, uint64_t *out_rp,
+                 hipStream_t s);
+int launch_xs_last(int n, int C, int Ho, int Wo, int cout_g, uint64_t *const o[4], const float *t_last, void *feat_frag,
+                   hipStream_t s);
 int launch_cp_to_rp(const uint16_t *cp, uint64_t *rp, int n, int C, int H, int W, hipStream_t s);
 int launch_rp_to_cp(const uint64_t *rp, uint16_t *cp, int n, int C, int H, int W, hipStream_t s);
 // feature planes (fragment order) -> float32 [n][(16g+k)*PP + pp] (reference Flatten order)

@@ -26,41 +26,75 @@ def dev():
     return torch.device("cuda", 0)
 
 
-@pytest.fixture(scope="module")
-def model(dev):
-    spec, st = spec_and_state("small")
-    m = ttnet.TT_vf_19lv3_imgnet_small(args_for("small"))
-    m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in st.items()}, strict=True)
-    m = m.to(dev).eval()
-    with torch.no_grad():
-        m(torch.from_numpy(synth.synth_images(1)).to(dev))       # builds the plan and the tables
-    torch.cuda.synchronize()
-    return m
+CLASSES = {"small": ttnet.TT_vf_19lv3_imgnet_small, "xsmall": ttnet.TT_vf_19lv3_imgnet_xsmall}
+_MODELS, _TAPS = {}, {}
+
+
+@pytest.fixture(scope="module", params=["small", "xsmall"])
+def variant(request):
+    return request.param
+
+
+def _model(variant, dev):
+    if variant not in _MODELS:
+        spec, st = spec_and_state(variant)
+        m = CLASSES[variant](args_for(variant))
+        m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in st.items()}, strict=True)
+        m = m.to(dev).eval()
+        with torch.no_grad():
+            m(torch.from_numpy(synth.synth_images(1)).to(dev))       # builds the plan and the tables
+        torch.cuda.synchronize()
+        _MODELS[variant] = m
+    return _MODELS[variant]
 
 
 @pytest.fixture(scope="module")
-def oracle_taps():
+def model(variant, dev):
+    return _model(variant, dev)
+
+
+@pytest.fixture(scope="module")
+def small_model(dev):
+    return _model("small", dev)
+
+
+@pytest.fixture(scope="module")
+def oracle_taps(variant):
     """Reference-identical stages for the 8 golden images (the float oracle is pinned to the
     reference bit for bit by tests/test_oracle_golden.py)."""
-    spec, st = spec_and_state("small")
-    sd = OF.to_torch_state(st)
-    x = torch.from_numpy(synth.synth_images(8))
-    taps = {}
-    y = OF.forward(x, sd, spec, taps)
-    return y.numpy(), {k: v.numpy() for k, v in taps.items()}
+    if variant not in _TAPS:
+        spec, st = spec_and_state(variant)
+        sd = OF.to_torch_state(st)
+        x = torch.from_numpy(synth.synth_images(8))
+        taps = {}
+        y = OF.forward(x, sd, spec, taps)
+        _TAPS[variant] = (y.numpy(), {k: v.numpy() for k, v in taps.items()})
+    return _TAPS[variant]
 
 
-def test_library_is_the_native_one(model):
+def _stage_width(spec, stage):
+    h = 56
+    if stage == "features.3":
+        return h
+    for b in spec.blocks:
+        ho = b.conv1.out_hw(h, h)[0]
+        if stage.startswith(b.name):
+            return ho
+        h = ho
+    raise KeyError(stage)
+
+
+def test_library_is_the_native_one(small_model):
     assert _lib.load().ttnet_version().startswith(b"ttnet-mi355x")
-    assert model._any_plan().query("fcsize") == 16384
-    assert model._any_plan().query("n_state_tensors") == 174
+    assert small_model._any_plan().query("fcsize") == 16384
+    assert small_model._any_plan().query("n_state_tensors") == 174
 
 
-def test_truth_tables_match_float64_oracle(model):
+def test_truth_tables_match_float64_oracle(model, variant):
     """GPU-built tables == float64 numpy tables (hash), near-tie counts equal; and they
     differ from the reference's own float32 tables only at the listed near ties."""
-    j = golden_json("small")
-    spec, st = spec_and_state("small")
+    j = golden_json(variant)
+    spec, st = spec_and_state(variant)
     ties = model.near_ties()
     for b in spec.block_tts():
         info = j["luts"][b.name]
@@ -82,9 +116,9 @@ def test_truth_tables_match_float64_oracle(model):
         assert sha(np.packbits(patched, axis=1, bitorder="little")) == info["ref_sha256"], b.name
 
 
-def test_stem_bits(model, dev, oracle_taps):
+def test_stem_bits(model, variant, dev, oracle_taps):
     """Float stem: bits equal the reference except (possibly) at near ties."""
-    g = golden_npz("small")
+    g = golden_npz(variant)
     x = torch.from_numpy(synth.synth_images(8)).to(dev)
     with torch.no_grad():
         model(x)
@@ -99,10 +133,10 @@ def test_stem_bits(model, dev, oracle_taps):
     assert np.array_equal(rows[:2], g["rows:features.3"]) or len(diff) > 0
 
 
-def _with_reference_tables(model):
+def _with_reference_tables(model, variant):
     """Patch the GPU tables with the reference's own near-tie decisions (fixture)."""
-    j = golden_json("small")
-    spec, _ = spec_and_state("small")
+    j = golden_json(variant)
+    spec, _ = spec_and_state(variant)
     saved = {}
     for b in spec.block_tts():
         if b.last:
@@ -117,11 +151,11 @@ def _with_reference_tables(model):
     return saved
 
 
-def test_gate_path_bit_exact_and_logits(model, dev, oracle_taps):
+def test_gate_path_bit_exact_and_logits(model, variant, dev, oracle_taps):
     """Integer gate path from the reference's stem bits: every stage of every image is bit
     identical to the reference capture; logits within 1e-5; top-1 equal."""
-    g, j = golden_npz("small"), golden_json("small")
-    saved = _with_reference_tables(model)
+    g, j = golden_npz(variant), golden_json(variant)
+    saved = _with_reference_tables(model, variant)
     try:
         stem_rows = OB.pack_rows(oracle_taps[1]["features.3"].astype(np.uint8))
         assert sha(stem_rows) == j["stages"]["features.3"]["rows_sha256"]
@@ -135,33 +169,47 @@ def test_gate_path_bit_exact_and_logits(model, dev, oracle_taps):
             assert [sha(got[i]) for i in range(8)] == info["per_image_sha256"], stage
         feat = model.read_stage("flatten", 8)
         assert np.abs(feat[:2] - g["features_flat"]).max() <= 1e-5
-        assert np.abs(logits - g["logits"]).max() <= LOGIT_TOL
+        # Float head.  The reference's own float32 head is not exact: on these features it sits
+        # up to ~6e-6 (small) / ~1.1e-5 (xsmall) from the float64 evaluation of the same head,
+        # and moves by ~5e-6 with its thread count.  So: within 1e-5 of the exact head, and
+        # within 1e-5 + (the reference's own deviation from exact) of the reference capture.
+        spec, st = spec_and_state(variant)
+        exact = OB.head64(oracle_taps[1]["flatten"], st, f"features.{4 + len(spec.blocks) + 2}")
+        ref_dev = float(np.abs(g["logits"] - exact).max())
+        print(f"{variant}: |gpu-exact| {np.abs(logits - exact).max():.2e}  |ref-exact| {ref_dev:.2e}  "
+              f"|gpu-ref| {np.abs(logits - g['logits']).max():.2e}")
+        assert np.abs(logits - exact).max() <= LOGIT_TOL
+        assert np.abs(logits - g["logits"]).max() <= LOGIT_TOL + ref_dev
         assert np.array_equal(logits.argmax(1), g["argmax"])
     finally:
         for name, tab in saved.items():
             model.set_table(name, tab)
 
 
-def test_end_to_end_forward(model, dev, oracle_taps):
+def test_end_to_end_forward(model, variant, dev, oracle_taps):
     """model(inputs) exactly as main.py:261 calls it, GPU-built float64 tables."""
-    g = golden_npz("small")
+    g = golden_npz(variant)
+    spec, _ = spec_and_state(variant)
     x = torch.from_numpy(synth.synth_images(8)).to(dev)
     with torch.no_grad():
         y = model(x).cpu().numpy()
     # which images touch a table entry where float64 and the reference's float32 disagree?
     clean = np.ones(8, dtype=bool)
     for stage in ("features.4", "features.5"):
-        got = OB.unpack_rows(model.read_stage(stage, 8), 29 if stage.endswith("4") else 15)
+        got = OB.unpack_rows(model.read_stage(stage, 8), _stage_width(spec, stage))
         ref = oracle_taps[1][stage].astype(np.uint8)
         clean &= (got == ref).reshape(8, -1).all(axis=1)
     print(f"end to end: {int(clean.sum())}/8 images bit identical to the reference through the gate path")
     assert clean.sum() >= 6
-    assert np.abs(y[clean] - g["logits"][clean]).max() <= LOGIT_TOL
+    exact = OB.head64(oracle_taps[1]["flatten"], spec_and_state(variant)[1], f"features.{4 + len(spec.blocks) + 2}")
+    assert np.abs(y[clean] - exact[clean]).max() <= LOGIT_TOL
+    assert np.abs(y[clean] - g["logits"][clean]).max() <= LOGIT_TOL + float(np.abs(g["logits"] - exact).max())
     assert np.array_equal(y[clean].argmax(1), g["argmax"][clean])
     assert np.abs(y - g["logits"]).max() < 1e-2          # a near-tie flip moves logits a little, never far
 
 
-def test_full_batch_properties(model, dev):
+def test_full_batch_properties(small_model, dev):
+    model = small_model
     """BASELINE size (batch 256): determinism, batch-composition invariance of the integer
     path, and agreement of a 256-image forward with 8-image forwards."""
     n = 256
@@ -187,10 +235,10 @@ def test_full_batch_properties(model, dev):
     assert len(set(y1.argmax(1).tolist())) > 20          # the synthetic classifier is not degenerate
 
 
-def test_majority_and_padding_edges(model, dev):
+def test_majority_and_padding_edges(model, variant, dev):
     """Edge inputs of the integer path: all-zero and all-one stem bits, checked against the
     bit oracle with the GPU's own tables."""
-    spec, st = spec_and_state("small")
+    spec, st = spec_and_state(variant)
     luts = {b.name: model.get_table(b.name) for b in spec.block_tts()}
     for fill in (0, 1):
         bits = np.full((2, 64, 56, 56), fill, dtype=np.uint8)
@@ -206,8 +254,8 @@ def test_majority_and_padding_edges(model, dev):
         assert np.abs(y - ref).max() <= 2e-5
 
 
-def test_random_bits_against_bit_oracle(model, dev):
-    spec, st = spec_and_state("small")
+def test_random_bits_against_bit_oracle(model, variant, dev):
+    spec, st = spec_and_state(variant)
     luts = {b.name: model.get_table(b.name) for b in spec.block_tts()}
     rng = np.random.default_rng(7)
     bits = rng.integers(0, 2, size=(3, 64, 56, 56), dtype=np.uint8)
@@ -220,14 +268,16 @@ def test_random_bits_against_bit_oracle(model, dev):
         if stage == spec.blocks[-1].name:                 # float output of the last block: see "flatten"
             continue
         if stage == "flatten":
-            assert np.abs(model.read_stage("flatten", 3) - bt[stage]).max() <= 1e-6
+            # float32 table entries (float64 values rounded once) averaged in float32
+            assert np.abs(model.read_stage("flatten", 3) - bt[stage]).max() <= 2e-7 * max(1.0, np.abs(bt[stage]).max()) + 1e-6
         else:
             assert np.array_equal(model.read_stage(stage, 3), OB.pack_rows(bt[stage])), stage
     assert np.abs(y - ref).max() <= 2e-5
 
 
-def test_errors_are_loud(model, dev):
+def test_errors_are_loud(small_model, dev):
     import ctypes as C
+    model = small_model
     lib = _lib.load()
     plan = model._any_plan()
     x = torch.zeros((1, 3, 224, 224), device=dev)
@@ -247,9 +297,10 @@ def test_errors_are_loud(model, dev):
     assert lib.ttnet_forward(h, C.c_void_p(x.data_ptr()), 1, C.c_void_p(out.data_ptr()), None) == -2
     assert lib.ttnet_plan_finalize(h, None) == -2 and b"missing key" in lib.ttnet_last_error()
     lib.ttnet_plan_destroy(h)
-    for variant in (1, 2):                              # xsmall / full: loud, not silent
-        desc = _lib.NetDesc(variant, 8, 8, 1, 224, 224, 4, 0)
-        assert lib.ttnet_plan_create(C.byref(desc), 0, C.byref(h)) == -4
+    desc = _lib.NetDesc(2, 6, 10, 1, 224, 224, 4, 0)     # full (fan-in 30): loud, not silent
+    assert lib.ttnet_plan_create(C.byref(desc), 0, C.byref(h)) == -4
+    desc = _lib.NetDesc(0, 8, 6, 1, 224, 224, 4, 0)      # p = 48: no stem kernel
+    assert lib.ttnet_plan_create(C.byref(desc), 0, C.byref(h)) == -4
     with pytest.raises(RuntimeError):
         model(torch.zeros((1, 3, 32, 32), device=dev))
 
