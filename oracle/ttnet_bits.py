@@ -115,6 +115,32 @@ def apply_lut(x: np.ndarray, table: np.ndarray, b: BlockTTSpec) -> np.ndarray:
     return out.reshape(n_, g * b.cout_g, ho, wo)
 
 
+def apply_direct(x: np.ndarray, sd: Dict[str, np.ndarray], b: BlockTTSpec,
+                 near: Optional[Dict[str, np.ndarray]] = None) -> np.ndarray:
+    """Block_TT.forward (models/TT_FHE_SMALL.py:307-320) on bit inputs, evaluated directly in
+    float64 with an exact erf -- for blocks too wide to enumerate (fan-in 30 of the full
+    model) and as a cross-check of the tables.  Returns bits (uint8) or relu'd float32 (last).
+    ``near[b.name]`` receives the near-tie mask |pre| < NEAR_TIE."""
+    import torch
+    import torch.nn.functional as F
+    xt = torch.from_numpy(x.astype(np.float64))
+    if b.padding:
+        xt = F.pad(xt, (b.padding,) * 4)
+    w1 = torch.from_numpy(sd[f"{b.name}.conv1.weight"].astype(np.float64))
+    w2 = torch.from_numpy(sd[f"{b.name}.conv2.weight"].astype(np.float64))
+    s1, t1 = fold_bn(sd, f"{b.name}.bn1")
+    s2, t2 = fold_bn(sd, f"{b.name}.bn2")
+    h = F.conv2d(xt, w1, None, b.stride, 0, 1, b.groups).numpy()
+    h = gelu64(h * s1[None, :, None, None] + t1[None, :, None, None])
+    pre = F.conv2d(torch.from_numpy(h), w2, None, 1, 0, 1, b.groups).numpy()
+    pre = pre * s2[None, :, None, None] + t2[None, :, None, None]
+    if near is not None:
+        near[b.name] = np.abs(pre) < NEAR_TIE
+    if b.last:
+        return np.maximum(pre, 0.0).astype(np.float32)
+    return (pre >= 0).astype(np.uint8)
+
+
 def majority2x2(x: np.ndarray) -> np.ndarray:
     """act(AvgPool2d(2)(x) - 0.5): floor-cropped 2x2 windows, 1 iff at least 2 of 4 set
     (models/TT_general_imagenet_v2_small.py:93-94)."""
@@ -130,11 +156,16 @@ def _zpad(x: np.ndarray, p) -> np.ndarray:
 
 
 def multihead_block_bits(x: np.ndarray, luts: Dict[str, np.ndarray], blk: MultiHeadSpec, variant: str,
-                         taps: Optional[Dict[str, np.ndarray]] = None) -> np.ndarray:
-    """models/TT_general_imagenet_v2_small.py:78-148 on bits."""
-    out3 = apply_lut(x, luts[blk.conv3.name], blk.conv3)
-    out2 = apply_lut(x, luts[blk.conv2.name], blk.conv2)
-    out1 = apply_lut(x, luts[blk.conv1.name], blk.conv1)
+                         taps: Optional[Dict[str, np.ndarray]] = None, sd=None, near=None) -> np.ndarray:
+    """models/TT_general_imagenet_v2_small.py:78-148 on bits.  A Block_TT without an entry in
+    ``luts`` is evaluated directly (float64) from ``sd``."""
+    def run(inp, b):
+        if luts is not None and b.name in luts:
+            return apply_lut(inp, luts[b.name], b)
+        return apply_direct(inp, sd, b, near)
+    out3 = run(x, blk.conv3)
+    out2 = run(x, blk.conv2)
+    out1 = run(x, blk.conv1)
     out4 = majority2x2(x)
     out3 = majority2x2(out3)
     p1, p2, p34 = pad_table(variant)[x.shape[-1]]
@@ -144,7 +175,7 @@ def multihead_block_bits(x: np.ndarray, luts: Dict[str, np.ndarray], blk: MultiH
             taps[f"{blk.name}.{nm}"] = t
     n_, c, hh, ww = out1.shape
     outf = np.stack((out1, out2, out3, out4), axis=2).reshape(n_, 4 * c, hh, ww)   # channel 4c+branch
-    return apply_lut(outf, luts[blk.convf.name], blk.convf)
+    return run(outf, blk.convf)
 
 
 def build_all_luts(sd: Dict[str, np.ndarray], spec: VariantSpec):
@@ -164,11 +195,12 @@ def head64(feat: np.ndarray, sd: Dict[str, np.ndarray], head: str) -> np.ndarray
 
 
 def forward_from_stem_bits(bits: np.ndarray, sd: Dict[str, np.ndarray], spec: VariantSpec, luts,
-                           taps: Optional[Dict[str, np.ndarray]] = None) -> np.ndarray:
-    """Gate path + float tail from the binarised stem output. Returns float64 logits."""
+                           taps: Optional[Dict[str, np.ndarray]] = None, near=None) -> np.ndarray:
+    """Gate path + float tail from the binarised stem output. Returns float64 logits.
+    ``luts`` may be None (every block evaluated directly in float64)."""
     x = bits
     for blk in spec.blocks:
-        x = multihead_block_bits(x, luts, blk, spec.variant, taps)
+        x = multihead_block_bits(x, luts, blk, spec.variant, taps, sd, near)
         if taps is not None:
             taps[blk.name] = x
     n_, c, h, w = x.shape

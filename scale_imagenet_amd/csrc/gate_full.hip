@@ -1,0 +1,220 @@
+// Gate path of the full variant (fan-in 30): TT_vf_19lv3_imgnet,
+// models/TT_general_imagenet_v2.py:21-136 -- (6,5)/(5,6) depthwise windows, 30-channel
+// grouped 1x1 blocks.  A flat truth table would need 2^30 entries per output bit, so the
+// blocks are evaluated directly:  pad -> conv1 -> bn1 -> gelu -> conv2 -> bn2 -> (x >= 0)
+// (Block_TT.forward, models/TT_FHE_SMALL.py:307-320) on bit inputs, in float64 with an exact
+// erf -- the same arithmetic that defines the truth tables of the other variants
+// (lut_build.hip), so "the bit" means the same thing for every variant and is independent of
+// summation order (float32 re-ordering was measured to flip outputs).
+//
+// Everything stays on row-packed planes (uint64 per image row).  Bound: fp64 VALU
+// (~0.8 GFLOP per image); this first version is written for parity, not speed.
+
+#include "ttnet_common.h"
+
+namespace ttnet {
+
+namespace {
+
+__device__ inline double gelu_exact(double x) { return 0.5 * x * (1.0 + erf(x * 0.70710678118654752440)); }
+
+// ---- depthwise Block_TT: one input channel -> 8 mid -> 1 output ---------------------------------
+// grid (C, n-chunks); thread = (image, output row); weights of the channel in LDS.
+__global__ __launch_bounds__(256) void full_dw_kernel(FullDwArgs a) {
+  __shared__ double w1[8 * 36], s1[8], t1[8], w2[8], s2, t2;
+  const int c = blockIdx.x, nk = a.kh * a.kw;
+  for (int i = threadIdx.x; i < 8 * nk; i += blockDim.x) w1[i] = (double)a.w1[(size_t)c * 8 * nk + i];
+  if (threadIdx.x < 8) {
+    s1[threadIdx.x] = a.s1[c * 8 + threadIdx.x];
+    t1[threadIdx.x] = a.t1[c * 8 + threadIdx.x];
+    w2[threadIdx.x] = (double)a.w2[c * 8 + threadIdx.x];
+  }
+  if (threadIdx.x == 0) {
+    s2 = a.s2[c];
+    t2 = a.t2[c];
+  }
+  __syncthreads();
+  const int rows = a.n * a.ho;
+  for (int t = blockIdx.y * blockDim.x + threadIdx.x; t < rows; t += gridDim.y * blockDim.x) {
+    const int n = t / a.ho, oy = t % a.ho;
+    uint64_t r[6];
+    for (int kh = 0; kh < a.kh; ++kh) {
+      const int iy = oy * a.stride - a.pad + kh;
+      r[kh] = (iy >= 0 && iy < a.H) ? a.x_rp[((size_t)n * a.C + c) * a.H + iy] << a.pad : 0ull;   // bit 0 = column -pad
+    }
+    uint64_t out = 0;
+    for (int ox = 0; ox < a.wo; ++ox) {
+      double acc = 0.0;
+      for (int m = 0; m < 8; ++m) {
+        double s = 0.0;
+        for (int kh = 0; kh < a.kh; ++kh) {
+          const uint32_t bits = (uint32_t)(r[kh] >> (ox * a.stride));
+          for (int kw = 0; kw < a.kw; ++kw) s += ((bits >> kw) & 1u) ? w1[m * nk + kh * a.kw + kw] : 0.0;
+        }
+        acc = fma(gelu_exact(s * s1[m] + t1[m]), w2[m], acc);
+      }
+      const double pre = acc * s2 + t2;
+      out |= (uint64_t)(pre >= 0.0) << (ox + a.pad_l);
+    }
+    a.out[((size_t)n * a.C + c) * a.Ho + oy + a.pad_t] = out;
+  }
+}
+
+// ---- grouped 1x1 Block_TT with `cin` inputs per group ------------------------------------------
+// Input bit (group g, j): channel J = cin*g + j of either a plane tensor (conv3) or of the
+// interleaved concat of four branch tensors (convf: channel J -> branch J%4, channel J/4;
+// models/TT_general_imagenet_v2.py:131-135).  One wave = one image row; lanes = columns.
+// Output: bits (ballot -> row words) or, for the last block, relu'd float32.
+__global__ __launch_bounds__(256) void full_pw_kernel(FullPwArgs a) {
+  extern __shared__ __align__(16) double lds[];
+  const int g = blockIdx.x, cin = a.cin, mid = a.mid, cout = a.cout;
+  double *w1 = lds;                      // [mid][cin]
+  double *w2 = w1 + mid * cin;           // [cout][mid]
+  double *s1 = w2 + cout * mid, *t1 = s1 + mid, *s2 = t1 + mid, *t2 = s2 + cout;
+  for (int i = threadIdx.x; i < mid * cin; i += blockDim.x) w1[i] = (double)a.w1[(size_t)g * mid * cin + i];
+  for (int i = threadIdx.x; i < cout * mid; i += blockDim.x) w2[i] = (double)a.w2[(size_t)g * cout * mid + i];
+  for (int i = threadIdx.x; i < mid; i += blockDim.x) {
+    s1[i] = a.s1[g * mid + i];
+    t1[i] = a.t1[g * mid + i];
+  }
+  for (int i = threadIdx.x; i < cout; i += blockDim.x) {
+    s2[i] = a.s2[g * cout + i];
+    t2[i] = a.t2[g * cout + i];
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+  const int rows = a.n * a.H;
+  for (int t = blockIdx.y * nwaves + wave; t < rows; t += gridDim.y * nwaves) {
+    const int n = t / a.H, y = t % a.H;
+    const bool live = lane < a.W;
+    // this pixel's `cin` input bits
+    uint32_t in = 0;
+    for (int j = 0; j < cin; ++j) {
+      const int J = cin * g + j;
+      uint64_t row;
+      if (a.interleaved) row = a.src[J & 3][((size_t)n * a.Csrc + (J >> 2)) * a.H + y];
+      else row = a.src[0][((size_t)n * a.Csrc + J) * a.H + y];
+      in |= (uint32_t)((row >> lane) & 1ull) << j;
+    }
+    double acc[30];
+#pragma unroll
+    for (int o = 0; o < 30; ++o) acc[o] = 0.0;
+    for (int m = 0; m < mid; ++m) {
+      double s = 0.0;
+      const double *wr = w1 + m * cin;
+      for (int j = 0; j < cin; ++j) s += ((in >> j) & 1u) ? wr[j] : 0.0;
+      const double h = gelu_exact(s * s1[m] + t1[m]);
+#pragma unroll
+      for (int o = 0; o < 30; ++o)
+        if (o < cout) acc[o] = fma(h, w2[o * mid + m], acc[o]);
+    }
+#pragma unroll
+    for (int o = 0; o < 30; ++o) {
+      if (o >= cout) break;
+      const double pre = acc[o] * s2[o] + t2[o];
+      if (a.out_float) {
+        if (live) a.out_float[(((size_t)n * a.Cout + g * cout + o) * a.H + y) * a.W + lane] = (float)(pre > 0.0 ? pre : 0.0);
+      } else {
+        const uint64_t m64 = __ballot(live && pre >= 0.0);
+        if (lane == 0) a.out_rp[((size_t)n * a.Cout + g * cout + o) * a.H + y] = m64;
+      }
+    }
+  }
+}
+
+// act(AvgPool2d(2)(x) - 0.5): floor-cropped 2x2 majority on row-packed planes, placed at (pad_t, pad_l)
+__global__ void rp_majority_kernel(const uint64_t *x, uint64_t *out, int n, int C, int H, int W, int Ho, int pad_t,
+                                   int pad_l) {
+  const int Hp = H / 2, Wp = W / 2;
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (size_t)n * C * Hp) return;
+  const int py = t % Hp;
+  const size_t nc = t / Hp;
+  const uint64_t a = x[nc * H + 2 * py], b = x[nc * H + 2 * py + 1];
+  uint64_t r = 0;
+  for (int px = 0; px < Wp; ++px) {
+    const int cnt = __popcll((a >> (2 * px)) & 3ull) + __popcll((b >> (2 * px)) & 3ull);
+    r |= (uint64_t)(cnt >= 2) << (px + pad_l);
+  }
+  out[nc * Ho + py + pad_t] = r;
+}
+
+// AvgPool2d(2) (floor) of the last block's float output + exact 3-way bf16 split into lin1's
+// fragment order (feature channel ch, pooled pixel pp: k-step (ch/16)*PP + pp, k = ch%16)
+__global__ void full_pool_split_kernel(const float *x, uint16_t *feat_frag, int n, int C, int H, int W) {
+  const int Hp = H / 2, Wp = W / 2, PP = Hp * Wp, KS = (C / 16) * PP;
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (size_t)n * C * PP) return;
+  const int pp = t % PP, ch = (t / PP) % C, img = t / ((size_t)PP * C);
+  const int py = pp / Wp, px = pp % Wp;
+  const float *p = x + (((size_t)img * C + ch) * H + 2 * py) * W + 2 * px;
+  const float f = (((p[0] + p[1]) + p[W]) + p[W + 1]) * 0.25f;
+  uint32_t u = __float_as_uint(f);
+  u += 0x7FFFu + ((u >> 16) & 1u);
+  const uint32_t b1 = u >> 16;
+  const float r1 = f - __uint_as_float(b1 << 16);
+  u = __float_as_uint(r1);
+  u += 0x7FFFu + ((u >> 16) & 1u);
+  const uint32_t b2 = u >> 16;
+  const float r2 = r1 - __uint_as_float(b2 << 16);
+  u = __float_as_uint(r2);
+  u += 0x7FFFu + ((u >> 16) & 1u);
+  const uint32_t b3 = u >> 16;
+  const int ks = (ch / 16) * PP + pp, kk = ch % 16, ln = (img & 31) + 32 * (kk >> 3), j = kk & 7;
+  const size_t base = ((size_t)(img >> 5) * KS + ks) * 3;
+  feat_frag[((base + 0) * 64 + ln) * 8 + j] = (uint16_t)b1;
+  feat_frag[((base + 1) * 64 + ln) * 8 + j] = (uint16_t)b2;
+  feat_frag[((base + 2) * 64 + ln) * 8 + j] = (uint16_t)b3;
+}
+
+}  // namespace
+
+int launch_full_dw(const FullDwArgs &a, hipStream_t s) {
+  if (a.kh > 6 || a.kw > 6 || a.kh * a.kw > 36 || a.W + 2 * a.pad > 63) {
+    set_error("full_dw: unsupported window %dx%d", a.kh, a.kw);
+    return TTNET_E_UNSUPPORTED;
+  }
+  const int rows = a.n * a.ho;
+  const int chunks = std::max(1, std::min((rows + 255) / 256, std::max(1, 1024 / a.C)));
+  hipLaunchKernelGGL(full_dw_kernel, dim3(a.C, chunks), dim3(256), 0, s, a);
+  TT_HIP(hipGetLastError());
+  return TTNET_OK;
+}
+
+int launch_full_pw(const FullPwArgs &a, hipStream_t s) {
+  if (a.cin > 32 || a.cout > 30 || a.W > 64) {
+    set_error("full_pw: unsupported group %d -> %d", a.cin, a.cout);
+    return TTNET_E_UNSUPPORTED;
+  }
+  const size_t lds = sizeof(double) * ((size_t)a.mid * a.cin + (size_t)a.cout * a.mid + 2 * a.mid + 2 * a.cout);
+  if (lds > (size_t)kMaxLds) {
+    set_error("full_pw: weights (%zu B) exceed LDS", lds);
+    return TTNET_E_UNSUPPORTED;
+  }
+  if (lds > 64 * 1024)
+    TT_HIP(hipFuncSetAttribute((const void *)full_pw_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  const int rows = a.n * a.H;
+  const int chunks = std::max(1, std::min((rows + 3) / 4, std::max(1, 512 / a.groups)));
+  hipLaunchKernelGGL(full_pw_kernel, dim3(a.groups, chunks), dim3(256), lds, s, a);
+  TT_HIP(hipGetLastError());
+  return TTNET_OK;
+}
+
+int launch_rp_majority(const uint64_t *x, uint64_t *out, int n, int C, int H, int W, int Ho, int pad_t, int pad_l,
+                       hipStream_t s) {
+  const size_t t = (size_t)n * C * (H / 2);
+  hipLaunchKernelGGL(rp_majority_kernel, dim3((unsigned)((t + 255) / 256)), dim3(256), 0, s, x, out, n, C, H, W, Ho, pad_t,
+                     pad_l);
+  TT_HIP(hipGetLastError());
+  return TTNET_OK;
+}
+
+int launch_full_pool_split(const float *x, void *feat_frag, int n, int C, int H, int W, hipStream_t s) {
+  const size_t t = (size_t)n * C * (H / 2) * (W / 2);
+  hipLaunchKernelGGL(full_pool_split_kernel, dim3((unsigned)((t + 255) / 256)), dim3(256), 0, s, x, (uint16_t *)feat_frag, n, C,
+                     H, W);
+  TT_HIP(hipGetLastError());
+  return TTNET_OK;
+}
+
+}  // namespace ttnet

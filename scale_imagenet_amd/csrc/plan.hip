@@ -57,6 +57,7 @@ struct BlockTT {
 struct MultiHead {
   std::string name;
   int C = 0, H = 0, W = 0, Ho = 0, Wo = 0, off34 = 0, stride = 2;
+  uint64_t *c3_tmp = nullptr;    // full variant: conv3 output at input resolution, before the majority pool
   bool last = false;
   BlockTT c1, c2, c3, cf;
   uint16_t *o[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -95,6 +96,8 @@ struct ttnet_plan {
   std::vector<std::string> key_order;
   bool finalized = false;
   bool xs = false;                  // x-small variant: row-packed branch tensors, gate_xs.hip kernels
+  bool full = false;                // full variant (fan-in 30): direct float64 evaluation, gate_full.hip
+  float *last_float = nullptr;      // full variant: relu'd output of the last block before AvgPool2d
 
   // stem
   uint16_t *stem_wt = nullptr;      // bf16 x 3 split weights, fragment order
@@ -184,9 +187,8 @@ int build_geometry(ttnet_plan *pl) {
     kh = kw = 2; pad = 1; gsize = 4;
     pl->xs = true;
   } else if (d.variant == TTNET_FULL) {
-    set_error("variant full (fan-in 30) cannot be a flat truth table (2^30 entries per output bit); "
-              "its direct-arithmetic kernels are not built yet");
-    return TTNET_E_UNSUPPORTED;
+    gsize = 30; pad = 3;               // kernels (6,5) / (5,6): set per branch below
+    pl->full = true;
   } else {
     set_error("unknown variant %d", d.variant);
     return TTNET_E_INVALID;
@@ -201,8 +203,8 @@ int build_geometry(ttnet_plan *pl) {
   }
   const int p = d.nfilter * d.tfilter;
   pl->p = p;
-  if (p != 64) {
-    set_error("p = nfilter*tfilter = %d: this build has the p = 64 stem kernel only", p);
+  if (p > 64 || (!pl->full && p != 64)) {
+    set_error("p = nfilter*tfilter = %d: the stem kernel covers p <= 64 (and the table variants need p = 64)", p);
     return TTNET_E_UNSUPPORTED;
   }
   std::vector<int> cfg;
@@ -225,7 +227,18 @@ int build_geometry(ttnet_plan *pl) {
     const int out_planes = cfg[i];
     mh.last = (out_planes == cfg.back());
     mh.C = in_planes; mh.H = h; mh.W = w;
-    const int ho = (h + 2 * pad - kh) / 2 + 1, wo = (w + 2 * pad - kw) / 2 + 1;
+    int ho = (h + 2 * pad - kh) / 2 + 1, wo = (w + 2 * pad - kw) / 2 + 1;
+    if (pl->full) {
+      // models/TT_general_imagenet_v2.py:98-128: conv1 is (6,5), conv2 (5,6); at 29x29 they come
+      // out 15x16 / 16x15 and are padded (bottom / right) to 16x16, out3/out4 by (0,2,0,2)
+      if (w == 56) { mh.off34 = 1; ho = wo = 29; }
+      else if (w == 29) { mh.off34 = 0; ho = wo = 16; }
+      else if (w == 16) { mh.off34 = 0; ho = wo = 9; }
+      else {
+        set_error("%s: no branch-padding rule for width %d (full variant)", mh.name.c_str(), w);
+        return TTNET_E_UNSUPPORTED;
+      }
+    } else {
     // branch padding keyed by the input width (:98-139): out3/out4 are floor(h/2) wide
     if (w == 56) mh.off34 = 1;                       // pad0 = ZeroPad2d((1,0,1,0))
     else if (w == 29 || w == 15 || w == 8 || w == 16 || w == 30) mh.off34 = 0;   // pad2 = (0,1,0,1)
@@ -237,13 +250,15 @@ int build_geometry(ttnet_plan *pl) {
       set_error("%s: branch shapes do not line up (%dx%d -> %dx%d)", mh.name.c_str(), h, w, ho, wo);
       return TTNET_E_UNSUPPORTED;
     }
+    }
     mh.Ho = ho; mh.Wo = wo;
     if (in_planes % gsize) {
       set_error("in_channels must be divisible by groups (in_planes=%d, group size %d)", in_planes, gsize);
       return TTNET_E_INVALID;
     }
-    mh.c1.g = make_geom(mh.name + ".Block_conv1", in_planes, in_planes, kh, kw, 2, pad, in_planes, false);
-    mh.c2.g = make_geom(mh.name + ".Block_conv2", in_planes, in_planes, kh, kw, 2, pad, in_planes, false);
+    const int kh1 = pl->full ? 6 : kh, kw1 = pl->full ? 5 : kw, kh2 = pl->full ? 5 : kh, kw2 = pl->full ? 6 : kw;
+    mh.c1.g = make_geom(mh.name + ".Block_conv1", in_planes, in_planes, kh1, kw1, 2, pad, in_planes, false);
+    mh.c2.g = make_geom(mh.name + ".Block_conv2", in_planes, in_planes, kh2, kw2, 2, pad, in_planes, false);
     mh.c3.g = make_geom(mh.name + ".Block_conv3", in_planes, in_planes, 1, 1, 1, 0, in_planes / gsize, false);
     const int cf_out = mh.last ? 4 * in_planes : 2 * out_planes;
     mh.cf.g = make_geom(mh.name + ".Block_convf", 4 * in_planes, cf_out, 1, 1, 1, 0, 4 * in_planes / gsize, mh.last);
@@ -252,7 +267,8 @@ int build_geometry(ttnet_plan *pl) {
     add_block_tt(pl, mh.c3.g);
     add_tensor(pl, mh.name + ".act.grad_scale", {}, TTNET_F32, false);
     add_block_tt(pl, mh.cf.g);
-    // internal index orders
+    // internal index orders (table variants only)
+    if (!pl->full)
     for (BlockTT *b : {&mh.c1, &mh.c2, &mh.c3}) {
       b->perm.resize(b->g.nbits());
       for (int q = 0; q < b->g.nbits(); ++q) b->perm[q] = (uint8_t)q;
@@ -260,9 +276,11 @@ int build_geometry(ttnet_plan *pl) {
     // convf group = gsize/4 channels x 4 branches; reference interleave is channel 4c+branch (:144-147),
     // internal index bit = (gsize/4)*branch + channel-in-group
     const int nch = gsize / 4;
-    mh.cf.perm.resize(gsize);
-    for (int br = 0; br < 4; ++br)
-      for (int cl = 0; cl < nch; ++cl) mh.cf.perm[nch * br + cl] = (uint8_t)(4 * cl + br);
+    if (!pl->full) {
+      mh.cf.perm.resize(gsize);
+      for (int br = 0; br < 4; ++br)
+        for (int cl = 0; cl < nch; ++cl) mh.cf.perm[nch * br + cl] = (uint8_t)(4 * cl + br);
+    }
     pl->blocks.push_back(mh);
     h = ho; w = wo;
     in_planes = 2 * out_planes;
@@ -299,16 +317,19 @@ int allocate(ttnet_plan *pl) {
   for (size_t i = 0; i < pl->blocks.size(); ++i) {
     MultiHead &mh = pl->blocks[i];
     TT_TRY(dev_alloc(pl, &pl->x_rp[i], (size_t)nb * mh.C * mh.H, true, ws));
-    TT_TRY(dev_alloc(pl, &pl->x_cp[i], (size_t)nb * mh.H * mh.W * (mh.C / 16), true, ws));
+    TT_TRY(dev_alloc(pl, &pl->x_cp[i], pl->full ? 8 : (size_t)nb * mh.H * mh.W * (mh.C / 16), true, ws));
+    if (pl->full) TT_TRY(dev_alloc(pl, &mh.c3_tmp, (size_t)nb * mh.C * mh.H, true, ws));
     for (int b = 0; b < 4; ++b) {  // zeroed once: the branch-padding border is never written again
       const size_t words16 = (size_t)nb * mh.Ho * mh.Wo * (mh.C / 16), rows64 = (size_t)nb * mh.C * mh.Ho;
-      TT_TRY(dev_alloc(pl, &mh.o[b], pl->xs ? rows64 * 4 : words16, true, ws));
+      TT_TRY(dev_alloc(pl, &mh.o[b], (pl->xs || pl->full) ? rows64 * 4 : words16, true, ws));
     }
     for (BlockTT *b : {&mh.c1, &mh.c2, &mh.c3, &mh.cf}) {
       const BlockGeom &g = b->g;
-      TT_TRY(dev_alloc(pl, (uint8_t **)&b->table, g.table_bytes(), true, tb));
-      TT_TRY(dev_alloc(pl, &b->perm_dev, b->perm.size(), false));
-      TT_HIP(hipMemcpy(b->perm_dev, b->perm.data(), b->perm.size(), hipMemcpyHostToDevice));
+      if (!pl->full) {
+        TT_TRY(dev_alloc(pl, (uint8_t **)&b->table, g.table_bytes(), true, tb));
+        TT_TRY(dev_alloc(pl, &b->perm_dev, b->perm.size(), false));
+        TT_HIP(hipMemcpy(b->perm_dev, b->perm.data(), b->perm.size(), hipMemcpyHostToDevice));
+      }
       TT_TRY(dev_alloc(pl, &b->s1, (size_t)8 * g.in_planes, false));
       TT_TRY(dev_alloc(pl, &b->t1, (size_t)8 * g.in_planes, false));
       TT_TRY(dev_alloc(pl, &b->s2, g.out_planes, false));
@@ -318,6 +339,10 @@ int allocate(ttnet_plan *pl) {
   }
   const int nb_pad = (nb + 255) / 256 * 256;          // the lin1 GEMM walks whole 256-row tiles
   TT_TRY(dev_alloc(pl, &pl->feat, frag_elems(nb_pad, pl->fcsize), true, ws));
+  if (pl->full) {
+    const MultiHead &lb = pl->blocks.back();
+    TT_TRY(dev_alloc(pl, &pl->last_float, (size_t)nb * lb.cf.g.out_planes * lb.Ho * lb.Wo, true, ws));
+  }
   TT_TRY(dev_alloc(pl, &pl->w1p, (size_t)pl->inter * pl->fcsize, false));
   TT_TRY(dev_alloc(pl, &pl->w1f, frag_elems((pl->inter + 127) / 128 * 128, pl->fcsize), false));
   TT_TRY(dev_alloc(pl, &pl->bn_scale, pl->inter, false));
@@ -369,7 +394,7 @@ int build_table(ttnet_plan *pl, BlockTT &b, hipStream_t s) {
   TT_HIP(hipMemcpy(b.t1, t1.data(), t1.size() * 8, hipMemcpyHostToDevice));
   TT_HIP(hipMemcpy(b.s2, s2.data(), s2.size() * 8, hipMemcpyHostToDevice));
   TT_HIP(hipMemcpy(b.t2, t2.data(), t2.size() * 8, hipMemcpyHostToDevice));
-  if (b.user_table) return TTNET_OK;
+  if (b.user_table || pl->full) return TTNET_OK;
   TT_HIP(hipMemsetAsync(b.near_dev, 0, sizeof(unsigned), s));
   LutBuildArgs a{};
   a.w1 = (const float *)pl->tensors[b.g.name + ".conv1.weight"].dev;
@@ -423,10 +448,69 @@ GateBlockArgs gate_args(ttnet_plan *pl, size_t i, int n) {
 static const char *kS1Names[] = {"gate_stage1.f4", "gate_stage1.f5", "gate_stage1.f6", "gate_stage1.f7"};
 static const char *kPfNames[] = {"gate_pf.f4", "gate_pf.f5", "gate_pf.f6", "gate_pf.f7"};
 
+// One block of the full variant: direct float64 evaluation (gate_full.hip)
+int run_full_block(ttnet_plan *pl, size_t i, int n, hipStream_t s) {
+  MultiHead &mh = pl->blocks[i];
+  uint64_t *o64[4] = {(uint64_t *)mh.o[0], (uint64_t *)mh.o[1], (uint64_t *)mh.o[2], (uint64_t *)mh.o[3]};
+  auto wts = [&](const BlockTT &b, const char *leaf) { return (const float *)pl->tensors[b.g.name + leaf].dev; };
+  for (int br = 0; br < 2; ++br) {
+    const BlockTT &b = br ? mh.c2 : mh.c1;
+    FullDwArgs a{};
+    a.n = n; a.C = mh.C; a.H = mh.H; a.W = mh.W;
+    a.kh = b.g.kh; a.kw = b.g.kw; a.stride = b.g.stride; a.pad = b.g.pad;
+    a.ho = (mh.H + 2 * a.pad - a.kh) / a.stride + 1;
+    a.wo = (mh.W + 2 * a.pad - a.kw) / a.stride + 1;
+    a.Ho = mh.Ho; a.pad_t = 0; a.pad_l = 0;          // out1 / out2 only ever get bottom / right zero padding
+    a.x_rp = pl->x_rp[i];
+    a.w1 = wts(b, ".conv1.weight"); a.w2 = wts(b, ".conv2.weight");
+    a.s1 = b.s1; a.t1 = b.t1; a.s2 = b.s2; a.t2 = b.t2;
+    a.out = o64[br];
+    TT_TIMED(pl, br ? "full.conv2" : "full.conv1", s, launch_full_dw(a, s));
+  }
+  {
+    const BlockTT &b = mh.c3;
+    FullPwArgs a{};
+    a.n = n; a.H = mh.H; a.W = mh.W;
+    a.groups = b.g.groups; a.cin = b.g.cin_g(); a.mid = b.g.mid_g(); a.cout = b.g.cout_g(); a.Cout = b.g.out_planes;
+    a.Csrc = mh.C; a.interleaved = 0; a.src[0] = pl->x_rp[i];
+    a.w1 = wts(b, ".conv1.weight"); a.w2 = wts(b, ".conv2.weight");
+    a.s1 = b.s1; a.t1 = b.t1; a.s2 = b.s2; a.t2 = b.t2;
+    a.out_rp = mh.c3_tmp; a.out_float = nullptr;
+    TT_TIMED(pl, "full.conv3", s, launch_full_pw(a, s));
+    TT_TIMED(pl, "full.maj3", s,
+             launch_rp_majority(mh.c3_tmp, o64[2], n, mh.C, mh.H, mh.W, mh.Ho, mh.off34, mh.off34, s));
+    TT_TIMED(pl, "full.maj4", s,
+             launch_rp_majority(pl->x_rp[i], o64[3], n, mh.C, mh.H, mh.W, mh.Ho, mh.off34, mh.off34, s));
+  }
+  {
+    const BlockTT &b = mh.cf;
+    FullPwArgs a{};
+    a.n = n; a.H = mh.Ho; a.W = mh.Wo;
+    a.groups = b.g.groups; a.cin = b.g.cin_g(); a.mid = b.g.mid_g(); a.cout = b.g.cout_g(); a.Cout = b.g.out_planes;
+    a.Csrc = mh.C; a.interleaved = 1;
+    for (int k = 0; k < 4; ++k) a.src[k] = o64[k];
+    a.w1 = wts(b, ".conv1.weight"); a.w2 = wts(b, ".conv2.weight");
+    a.s1 = b.s1; a.t1 = b.t1; a.s2 = b.s2; a.t2 = b.t2;
+    if (mh.last) {
+      a.out_rp = nullptr; a.out_float = pl->last_float;
+      TT_TIMED(pl, "full.convf_last", s, launch_full_pw(a, s));
+      TT_TIMED(pl, "full.pool", s, launch_full_pool_split(pl->last_float, pl->feat, n, b.g.out_planes, mh.Ho, mh.Wo, s));
+    } else {
+      a.out_rp = pl->x_rp[i + 1]; a.out_float = nullptr;
+      TT_TIMED(pl, "full.convf", s, launch_full_pw(a, s));
+    }
+  }
+  return TTNET_OK;
+}
+
 int run_from_blocks(ttnet_plan *pl, int n, float *logits, hipStream_t s) {
   for (size_t i = 0; i < pl->blocks.size(); ++i) {
     MultiHead &mh = pl->blocks[i];
     GateBlockArgs a = gate_args(pl, i, n);
+    if (pl->full) {
+      TT_TRY(run_full_block(pl, i, n, s));
+      continue;
+    }
     if (pl->xs) {
       uint64_t *const o64[4] = {(uint64_t *)mh.o[0], (uint64_t *)mh.o[1], (uint64_t *)mh.o[2], (uint64_t *)mh.o[3]};
       TT_TIMED(pl, kS1Names[i], s, launch_xs_branches(a, mh.c3.table, o64, s));
@@ -579,7 +663,7 @@ int ttnet_plan_finalize(ttnet_plan *pl, void *stream) {
     std::vector<float> w;
     TT_TRY(fetch(pl->tensors["features.1.weight"], w));
     std::vector<uint16_t> wf(stem_split_weights_elems());
-    stem_split_weights(w.data(), wf.data());
+    stem_split_weights(w.data(), pl->p, wf.data());
     TT_HIP(hipMemcpy(pl->stem_wt, wf.data(), wf.size() * 2, hipMemcpyHostToDevice));
     std::vector<double> sc, sh;
     TT_TRY(fold_bn(pl, "features.2", sc, sh));
@@ -600,7 +684,7 @@ int ttnet_plan_finalize(ttnet_plan *pl, void *stream) {
   TT_HIP(hipStreamSynchronize(s));
   for (auto &mh : pl->blocks)
     for (BlockTT *b : {&mh.c1, &mh.c2, &mh.c3, &mh.cf}) {
-      if (b->user_table) continue;
+      if (b->user_table || pl->full) continue;
       unsigned v = 0;
       TT_HIP(hipMemcpy(&v, b->near_dev, sizeof(v), hipMemcpyDeviceToHost));
       b->near_ties = v;
@@ -614,7 +698,8 @@ int ttnet_forward(ttnet_plan *pl, const float *x_dev, int64_t n, float *logits_d
   hipStream_t s = (hipStream_t)stream;
   pl->timing_used = 0;
   TT_TIMED(pl, "stem", s,
-           launch_stem(x_dev, pl->stem_wt, pl->stem_scale, pl->stem_shift, pl->x_rp[0], pl->x_cp[0], (int)n, pl->p, s));
+           launch_stem(x_dev, pl->stem_wt, pl->stem_scale, pl->stem_shift, pl->x_rp[0], pl->full ? nullptr : pl->x_cp[0], (int)n,
+                       pl->p, s));
   return run_from_blocks(pl, (int)n, logits_dev, s);
 }
 
@@ -625,7 +710,7 @@ int ttnet_forward_from_stem_bits(ttnet_plan *pl, const uint64_t *rows_dev, int64
   pl->timing_used = 0;
   const MultiHead &b0 = pl->blocks[0];
   TT_HIP(hipMemcpyAsync(pl->x_rp[0], rows_dev, (size_t)n * b0.C * b0.H * 8, hipMemcpyDeviceToDevice, s));
-  TT_TRY(launch_rp_to_cp(pl->x_rp[0], pl->x_cp[0], (int)n, b0.C, b0.H, b0.W, s));
+  if (!pl->full && !pl->xs) TT_TRY(launch_rp_to_cp(pl->x_rp[0], pl->x_cp[0], (int)n, b0.C, b0.H, b0.W, s));
   return run_from_blocks(pl, (int)n, logits_dev, s);
 }
 
@@ -658,7 +743,7 @@ int ttnet_read_stage(ttnet_plan *pl, const char *stage, int64_t n, void *dst, si
     for (int b = 0; b < 4; ++b) {
       if (st == mh.name + ".out" + std::to_string(b + 1)) {
         const size_t words = (size_t)n * mh.C * mh.Ho;
-        if (pl->xs) return copy_out(mh.o[b], words * 8);
+        if (pl->xs || pl->full) return copy_out(mh.o[b], words * 8);
         uint64_t *tmp = nullptr;
         TT_HIP(hipMalloc((void **)&tmp, words * 8));
         int r = launch_cp_to_rp(mh.o[b], tmp, (int)n, mh.C, mh.Ho, mh.Wo, s);
@@ -690,6 +775,10 @@ int ttnet_plan_get_table(ttnet_plan *pl, const char *name, void *dst_host, size_
   if (!b) {
     set_error("no Block_TT named %s", name);
     return TTNET_E_INVALID;
+  }
+  if (pl->full) {
+    set_error("the full variant (fan-in 30) has no truth tables: 2^30 entries per output bit");
+    return TTNET_E_UNSUPPORTED;
   }
   if (!pl->finalized) {
     set_error("get_table before finalize");
@@ -734,6 +823,10 @@ int ttnet_plan_set_table(ttnet_plan *pl, const char *name, const void *src_host,
   if (!b) {
     set_error("no Block_TT named %s", name);
     return TTNET_E_INVALID;
+  }
+  if (pl->full) {
+    set_error("the full variant (fan-in 30) has no truth tables: 2^30 entries per output bit");
+    return TTNET_E_UNSUPPORTED;
   }
   const BlockGeom &g = b->g;
   const size_t entries = (size_t)1 << g.nbits();

@@ -53,16 +53,16 @@ __device__ inline float bf16_f32(uint32_t b) { return __uint_as_float(b << 16); 
 __global__ __launch_bounds__(256, 2) void stem_mfma_kernel(const float *__restrict__ x, const uint4 *__restrict__ wfrag,
                                                           const float *__restrict__ scale,
                                                           const float *__restrict__ shift, uint64_t *__restrict__ rp,
-                                                          uint16_t *__restrict__ cp) {
+                                                          uint16_t *__restrict__ cp, int p) {
   __shared__ __align__(16) uint16_t tile[3 * PLANE];   // [plane][c][row][col] bf16
   __shared__ float s_scale[64], s_shift[64];
   __shared__ uint32_t stage[64][NT + 2];                // row-layout staging: bit = pixel within the block
   const int n = blockIdx.y, oy0 = blockIdx.x * SR;
   const int H = 224, W = 224;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  if (threadIdx.x < 64) {
-    s_scale[threadIdx.x] = scale[threadIdx.x];
-    s_shift[threadIdx.x] = shift[threadIdx.x];
+  if (threadIdx.x < 64) {                               // channels >= p: zero weights, never stored
+    s_scale[threadIdx.x] = (int)threadIdx.x < p ? scale[threadIdx.x] : 0.f;
+    s_shift[threadIdx.x] = (int)threadIdx.x < p ? shift[threadIdx.x] : 0.f;
     stage[threadIdx.x][NT] = 0;
     stage[threadIdx.x][NT + 1] = 0;
   }
@@ -221,7 +221,7 @@ __global__ __launch_bounds__(256, 2) void stem_mfma_kernel(const float *__restri
       pw |= (uint32_t)__shfl_xor((int)pw, 32);
       // half-wave 0 stores group 2m, half-wave 1 group 2m+1
       const int q = 2 * m + h;
-      cp[(((size_t)n * 4 + q) * 56 + oy0 + oyl) * 56 + ox] = (uint16_t)(h ? (pw >> 16) : pw);
+      if (cp) cp[(((size_t)n * 4 + q) * 56 + oy0 + oyl) * 56 + ox] = (uint16_t)(h ? (pw >> 16) : pw);
     });
     if (lane < 32) {                        // lanes 0-31 of the ballot: channel chl, lanes 32-63: chl + 4
       const int m = lane >> 4, r = lane & 15;
@@ -238,7 +238,7 @@ __global__ __launch_bounds__(256, 2) void stem_mfma_kernel(const float *__restri
     const uint64_t hi = stage[ch][w0 + 2];
     uint64_t v = lo >> s;
     if (s) v |= hi << (64 - s);
-    rp[((size_t)n * 64 + ch) * 56 + oy0 + row] = v & ((1ull << 56) - 1ull);
+    if (ch < p) rp[((size_t)n * p + ch) * 56 + oy0 + row] = v & ((1ull << 56) - 1ull);
   }
 }
 
@@ -247,7 +247,7 @@ __global__ __launch_bounds__(256, 2) void stem_mfma_kernel(const float *__restri
 // Host side of the operand split: w [64][3][7][7] float32 -> fragment-ordered bf16 planes
 // [ks][plane][mtile][lane][8]: lane l of M-tile m holds channel 32m + (l&31), k = 16ks + 8(l>>5) + j,
 // k = ((c*7 + kh)*8 + kw); kw = 7 and the 22nd (c,kh) row carry zero weights.
-void stem_split_weights(const float *w, uint16_t *out) {
+void stem_split_weights(const float *w, int p, uint16_t *out) {
   auto rne = [](float x) {
     uint32_t u;
     memcpy(&u, &x, 4);
@@ -266,7 +266,7 @@ void stem_split_weights(const float *w, uint16_t *out) {
         for (int j = 0; j < 8; ++j) {
           const int ch = 32 * m + (l & 31), R = 2 * ks + (l >> 5), kw = j;
           float v = 0.f;
-          if (R < 21 && kw < 7) v = w[(size_t)ch * 147 + R * 7 + kw];     // R = c*7 + kh
+          if (ch < p && R < 21 && kw < 7) v = w[(size_t)ch * 147 + R * 7 + kw];     // R = c*7 + kh
           const uint16_t b1 = rne(v);
           const float r1 = v - tof(b1);
           const uint16_t b2 = rne(r1);
@@ -280,11 +280,11 @@ size_t stem_split_weights_elems() { return (size_t)KSTEPS * 3 * 2 * 64 * 8; }
 
 int launch_stem(const float *x, const void *wfrag, const float *scale, const float *shift, uint64_t *rp,
                 uint16_t *cp, int n, int p, hipStream_t s) {
-  if (p != 64) {
-    set_error("stem: this build has the p = 64 kernel only (p=%d)", p);
+  if (p < 1 || p > 64 || (cp && p != 64)) {
+    set_error("stem: p=%d outside [1,64] (channel words need p = 64)", p);
     return TTNET_E_UNSUPPORTED;
   }
-  hipLaunchKernelGGL(stem_mfma_kernel, dim3(56 / SR, n), dim3(256), 0, s, x, (const uint4 *)wfrag, scale, shift, rp, cp);
+  hipLaunchKernelGGL(stem_mfma_kernel, dim3(56 / SR, n), dim3(256), 0, s, x, (const uint4 *)wfrag, scale, shift, rp, cp, p);
   TT_HIP(hipGetLastError());
   return TTNET_OK;
 }

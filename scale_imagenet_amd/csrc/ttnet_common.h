@@ -4,6 +4,7 @@
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <algorithm>
 #include <string>
 #include <type_traits>
 #include <vector>
@@ -96,7 +97,7 @@ int launch_lut_build(const LutBuildArgs &a, hipStream_t s);
 // wfrag: the conv weights split into three bf16 planes in MFMA fragment order (stem_split_weights)
 int launch_stem(const float *x, const void *wfrag, const float *scale, const float *shift, uint64_t *rp,
                 uint16_t *cp, int n, int p, hipStream_t s);
-void stem_split_weights(const float *w /*[64][3][7][7]*/, uint16_t *out);
+void stem_split_weights(const float *w /*[p][3][7][7]*/, int p, uint16_t *out);
 size_t stem_split_weights_elems();
 
 // gate.hip
@@ -126,6 +127,34 @@ int launch_xs_pf(int n, int C, int Ho, int Wo, int cout_g, uint64_t *const o[4],
                  hipStream_t s);
 int launch_xs_last(int n, int C, int Ho, int Wo, int cout_g, uint64_t *const o[4], const float *t_last, void *feat_frag,
                    hipStream_t s);
+// full variant (fan-in 30, gate_full.hip): direct float64 evaluation on row-packed planes
+struct FullDwArgs {
+  int n, C, H, W;           // input planes
+  int kh, kw, stride, pad;
+  int ho, wo;               // conv output size
+  int Ho;                   // rows per plane of `out` (after the branch padding)
+  int pad_t, pad_l;         // where the conv output sits inside the padded plane
+  const uint64_t *x_rp;
+  const float *w1, *w2;     // conv1.weight [8C][kh*kw], conv2.weight [C][8]
+  const double *s1, *t1, *s2, *t2;
+  uint64_t *out;            // [n][C][Ho]
+};
+struct FullPwArgs {
+  int n, H, W;              // pixel grid
+  int groups, cin, mid, cout, Cout;
+  int Csrc;                 // channels per source tensor
+  int interleaved;          // 0: src[0] planes; 1: channel J -> src[J%4] plane J/4 (the 4-branch concat)
+  const uint64_t *src[4];
+  const float *w1, *w2;     // conv1.weight [G*mid][cin], conv2.weight [G*cout][mid]
+  const double *s1, *t1, *s2, *t2;
+  uint64_t *out_rp;         // [n][Cout][H]  (binarised blocks)
+  float *out_float;         // [n][Cout][H][W] relu'd (last block), or nullptr
+};
+int launch_full_dw(const FullDwArgs &a, hipStream_t s);
+int launch_full_pw(const FullPwArgs &a, hipStream_t s);
+int launch_rp_majority(const uint64_t *x, uint64_t *out, int n, int C, int H, int W, int Ho, int pad_t, int pad_l,
+                       hipStream_t s);
+int launch_full_pool_split(const float *x, void *feat_frag, int n, int C, int H, int W, hipStream_t s);
 int launch_cp_to_rp(const uint16_t *cp, uint64_t *rp, int n, int C, int H, int W, hipStream_t s);
 int launch_rp_to_cp(const uint64_t *rp, uint16_t *cp, int n, int C, int H, int W, hipStream_t s);
 // feature planes (fragment order) -> float32 [n][(16g+k)*PP + pp] (reference Flatten order)

@@ -68,6 +68,8 @@ class MultiHeadSpec:
     conv2: BlockTTSpec
     conv3: BlockTTSpec
     convf: BlockTTSpec
+    in_hw: Tuple[int, int] = (0, 0)      # block input size
+    out_hw: Tuple[int, int] = (0, 0)     # common size of the four branches after their padding
 
 
 @dataclass(frozen=True)
@@ -169,7 +171,6 @@ def make_spec(variant: str = "small", nfilter: int = 8, tfilter: int = 8, layers
         c3 = BlockTTSpec(f"{name}.Block_conv3", in_planes, in_planes, 1, 1, 1, 0, g3)
         cf_out = 4 * in_planes if last else 2 * out_planes
         cf = BlockTTSpec(f"{name}.Block_convf", 4 * in_planes, cf_out, 1, 1, 1, 0, gf, last=last)
-        blocks.append(MultiHeadSpec(name, in_planes, out_planes, stride, last, c1, c2, c3, cf))
         if stride != 2:
             raise NotImplementedError("stride-1 multi-head blocks (--layers 3/4) are not built yet")
         tbl = pad_table(variant)
@@ -184,6 +185,7 @@ def make_spec(variant: str = "small", nfilter: int = 8, tfilter: int = 8, layers
         s34 = (h // 2 + p34[2] + p34[3], w // 2 + p34[0] + p34[1])
         if not (s1 == s2 == s34):
             raise ValueError(f"{name}: branch shapes differ after padding: {s1} {s2} {s34}")
+        blocks.append(MultiHeadSpec(name, in_planes, out_planes, stride, last, c1, c2, c3, cf, (h, w), s1))
         h, w = s1
         in_planes = 2 * out_planes
     c_last = blocks[-1].convf.out_planes

@@ -255,17 +255,13 @@ class _TTNetBase(nn.Module):
         return out
 
     def _stage_shape(self, stage: str):
-        blocks = self.spec.blocks
         if stage == "features.3":
             return self.spec.p, 56
-        h = 56
-        for i, b in enumerate(blocks):
-            ho = b.conv1.out_hw(h, h)[0]
+        for b in self.spec.blocks:
             if stage.startswith(b.name + ".out"):
-                return b.in_planes, ho
+                return b.in_planes, b.out_hw[0]
             if stage == b.name:
-                return b.convf.out_planes, ho
-            h = ho
+                return b.convf.out_planes, b.out_hw[0]
         raise KeyError(stage)
 
     def get_table(self, name: str) -> np.ndarray:

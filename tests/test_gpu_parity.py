@@ -26,11 +26,12 @@ def dev():
     return torch.device("cuda", 0)
 
 
-CLASSES = {"small": ttnet.TT_vf_19lv3_imgnet_small, "xsmall": ttnet.TT_vf_19lv3_imgnet_xsmall}
+CLASSES = {"small": ttnet.TT_vf_19lv3_imgnet_small, "xsmall": ttnet.TT_vf_19lv3_imgnet_xsmall,
+           "full": ttnet.TT_vf_19lv3_imgnet}
 _MODELS, _TAPS = {}, {}
 
 
-@pytest.fixture(scope="module", params=["small", "xsmall"])
+@pytest.fixture(scope="module", params=["small", "xsmall", "full"])
 def variant(request):
     return request.param
 
@@ -65,7 +66,7 @@ def oracle_taps(variant):
     if variant not in _TAPS:
         spec, st = spec_and_state(variant)
         sd = OF.to_torch_state(st)
-        x = torch.from_numpy(synth.synth_images(8))
+        x = torch.from_numpy(synth.synth_images(int(golden_npz(variant)["n_images"])))
         taps = {}
         y = OF.forward(x, sd, spec, taps)
         _TAPS[variant] = (y.numpy(), {k: v.numpy() for k, v in taps.items()})
@@ -73,14 +74,11 @@ def oracle_taps(variant):
 
 
 def _stage_width(spec, stage):
-    h = 56
     if stage == "features.3":
-        return h
+        return 56
     for b in spec.blocks:
-        ho = b.conv1.out_hw(h, h)[0]
         if stage.startswith(b.name):
-            return ho
-        h = ho
+            return b.out_hw[1]
     raise KeyError(stage)
 
 
@@ -93,6 +91,10 @@ def test_library_is_the_native_one(small_model):
 def test_truth_tables_match_float64_oracle(model, variant):
     """GPU-built tables == float64 numpy tables (hash), near-tie counts equal; and they
     differ from the reference's own float32 tables only at the listed near ties."""
+    if variant == "full":           # fan-in 30: no tables exist (2^30 entries per output bit)
+        with pytest.raises(_lib.TTNetError, match="no truth tables"):
+            model.get_table("features.4.Block_conv3")
+        return
     j = golden_json(variant)
     spec, st = spec_and_state(variant)
     ties = model.near_ties()
@@ -119,10 +121,11 @@ def test_truth_tables_match_float64_oracle(model, variant):
 def test_stem_bits(model, variant, dev, oracle_taps):
     """Float stem: bits equal the reference except (possibly) at near ties."""
     g = golden_npz(variant)
-    x = torch.from_numpy(synth.synth_images(8)).to(dev)
+    n = int(g["n_images"])
+    x = torch.from_numpy(synth.synth_images(n)).to(dev)
     with torch.no_grad():
         model(x)
-    rows = model.read_stage("features.3", 8)
+    rows = model.read_stage("features.3", n)
     ref_bits = oracle_taps[1]["features.3"].astype(np.uint8)
     bits = OB.unpack_rows(rows, 56)
     diff = np.argwhere(bits != ref_bits)
@@ -138,6 +141,8 @@ def _with_reference_tables(model, variant):
     j = golden_json(variant)
     spec, _ = spec_and_state(variant)
     saved = {}
+    if variant == "full":
+        return saved
     for b in spec.block_tts():
         if b.last:
             continue
@@ -155,6 +160,7 @@ def test_gate_path_bit_exact_and_logits(model, variant, dev, oracle_taps):
     """Integer gate path from the reference's stem bits: every stage of every image is bit
     identical to the reference capture; logits within 1e-5; top-1 equal."""
     g, j = golden_npz(variant), golden_json(variant)
+    n = int(g["n_images"])
     saved = _with_reference_tables(model, variant)
     try:
         stem_rows = OB.pack_rows(oracle_taps[1]["features.3"].astype(np.uint8))
@@ -165,9 +171,9 @@ def test_gate_path_bit_exact_and_logits(model, variant, dev, oracle_taps):
         for stage, info in j["stages"].items():
             if stage in ("flatten", "features.3"):
                 continue
-            got = model.read_stage(stage, 8)
-            assert [sha(got[i]) for i in range(8)] == info["per_image_sha256"], stage
-        feat = model.read_stage("flatten", 8)
+            got = model.read_stage(stage, n)
+            assert [sha(got[i]) for i in range(n)] == info["per_image_sha256"], stage
+        feat = model.read_stage("flatten", n)
         assert np.abs(feat[:2] - g["features_flat"]).max() <= 1e-5
         # Float head.  The reference's own float32 head is not exact: on these features it sits
         # up to ~6e-6 (small) / ~1.1e-5 (xsmall) from the float64 evaluation of the same head,
@@ -189,18 +195,19 @@ def test_gate_path_bit_exact_and_logits(model, variant, dev, oracle_taps):
 def test_end_to_end_forward(model, variant, dev, oracle_taps):
     """model(inputs) exactly as main.py:261 calls it, GPU-built float64 tables."""
     g = golden_npz(variant)
+    n = int(g["n_images"])
     spec, _ = spec_and_state(variant)
-    x = torch.from_numpy(synth.synth_images(8)).to(dev)
+    x = torch.from_numpy(synth.synth_images(n)).to(dev)
     with torch.no_grad():
         y = model(x).cpu().numpy()
     # which images touch a table entry where float64 and the reference's float32 disagree?
-    clean = np.ones(8, dtype=bool)
+    clean = np.ones(n, dtype=bool)
     for stage in ("features.4", "features.5"):
-        got = OB.unpack_rows(model.read_stage(stage, 8), _stage_width(spec, stage))
+        got = OB.unpack_rows(model.read_stage(stage, n), _stage_width(spec, stage))
         ref = oracle_taps[1][stage].astype(np.uint8)
-        clean &= (got == ref).reshape(8, -1).all(axis=1)
-    print(f"end to end: {int(clean.sum())}/8 images bit identical to the reference through the gate path")
-    assert clean.sum() >= 6
+        clean &= (got == ref).reshape(n, -1).all(axis=1)
+    print(f"end to end: {int(clean.sum())}/{n} images bit identical to the reference through the gate path")
+    assert clean.sum() >= n - 2
     exact = OB.head64(oracle_taps[1]["flatten"], spec_and_state(variant)[1], f"features.{4 + len(spec.blocks) + 2}")
     assert np.abs(y[clean] - exact[clean]).max() <= LOGIT_TOL
     assert np.abs(y[clean] - g["logits"][clean]).max() <= LOGIT_TOL + float(np.abs(g["logits"] - exact).max())
@@ -239,9 +246,9 @@ def test_majority_and_padding_edges(model, variant, dev):
     """Edge inputs of the integer path: all-zero and all-one stem bits, checked against the
     bit oracle with the GPU's own tables."""
     spec, st = spec_and_state(variant)
-    luts = {b.name: model.get_table(b.name) for b in spec.block_tts()}
+    luts = None if variant == "full" else {b.name: model.get_table(b.name) for b in spec.block_tts()}
     for fill in (0, 1):
-        bits = np.full((2, 64, 56, 56), fill, dtype=np.uint8)
+        bits = np.full((2, spec.p, 56, 56), fill, dtype=np.uint8)
         bits[1, ::3, ::5, ::7] ^= 1
         rows_t = torch.from_numpy(OB.pack_rows(bits).view(np.int64)).to(dev)
         with torch.no_grad():
@@ -256,9 +263,9 @@ def test_majority_and_padding_edges(model, variant, dev):
 
 def test_random_bits_against_bit_oracle(model, variant, dev):
     spec, st = spec_and_state(variant)
-    luts = {b.name: model.get_table(b.name) for b in spec.block_tts()}
+    luts = None if variant == "full" else {b.name: model.get_table(b.name) for b in spec.block_tts()}
     rng = np.random.default_rng(7)
-    bits = rng.integers(0, 2, size=(3, 64, 56, 56), dtype=np.uint8)
+    bits = rng.integers(0, 2, size=(3, spec.p, 56, 56), dtype=np.uint8)
     rows_t = torch.from_numpy(OB.pack_rows(bits).view(np.int64)).to(dev)
     with torch.no_grad():
         y = model.forward_from_stem_bits(rows_t).cpu().numpy()
@@ -297,9 +304,9 @@ def test_errors_are_loud(small_model, dev):
     assert lib.ttnet_forward(h, C.c_void_p(x.data_ptr()), 1, C.c_void_p(out.data_ptr()), None) == -2
     assert lib.ttnet_plan_finalize(h, None) == -2 and b"missing key" in lib.ttnet_last_error()
     lib.ttnet_plan_destroy(h)
-    desc = _lib.NetDesc(2, 6, 10, 1, 224, 224, 4, 0)     # full (fan-in 30): loud, not silent
-    assert lib.ttnet_plan_create(C.byref(desc), 0, C.byref(h)) == -4
-    desc = _lib.NetDesc(0, 8, 6, 1, 224, 224, 4, 0)      # p = 48: no stem kernel
+    desc = _lib.NetDesc(2, 8, 8, 1, 224, 224, 4, 0)      # full at p = 64: in_channels not divisible by groups
+    assert lib.ttnet_plan_create(C.byref(desc), 0, C.byref(h)) == -1
+    desc = _lib.NetDesc(0, 8, 6, 1, 224, 224, 4, 0)      # small at p = 48: the table variants need p = 64
     assert lib.ttnet_plan_create(C.byref(desc), 0, C.byref(h)) == -4
     with pytest.raises(RuntimeError):
         model(torch.zeros((1, 3, 32, 32), device=dev))
