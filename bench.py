@@ -133,6 +133,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=256, help="images per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--variant", default="small", choices=["small", "xsmall", "full"],
+                    help="small = BASELINE.json configs[1] (the headline); the others are parity-test configs")
     args = ap.parse_args()
 
     rank, world, local_rank = init_from_env("nccl")
@@ -142,9 +144,12 @@ def main():
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
 
-    spec = make_spec("small")
+    vargs = dict(nfilter=6, tfilter=10) if args.variant == "full" else dict(nfilter=8, tfilter=8)
+    spec = make_spec(args.variant, **vargs)
     st = synth.synth_state_dict(spec)
-    model = ttnet.TT_vf_19lv3_imgnet_small(Namespace(nfilter=8, tfilter=8, layers=1, groups=[1, None, 4, None]))
+    cls = {"small": ttnet.TT_vf_19lv3_imgnet_small, "xsmall": ttnet.TT_vf_19lv3_imgnet_xsmall,
+           "full": ttnet.TT_vf_19lv3_imgnet}[args.variant]
+    model = cls(Namespace(layers=1, groups=[1, None, 4, None], **vargs))
     model.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in st.items()}, strict=True)
     model = model.to(dev).eval().reserve(args.batch)
 
@@ -186,8 +191,8 @@ def main():
     avg_ms = {k: v / args.steps for k, v in acc.items()}
 
     if rank == 0:
-        models = kernel_models(B)
-        traffic, traffic_src = measured_traffic(B)
+        models = kernel_models(B) if args.variant == "small" else {}
+        traffic, traffic_src = measured_traffic(B) if args.variant == "small" else ({}, None)
         kernels = []
         for k, ms in avg_ms.items():
             bound, units = models.get(k, ("hbm", 0.0))
@@ -201,8 +206,10 @@ def main():
                 ach, peak, unit = units / (ms * 1e-3) / 1e9, HBM_PEAK_GBS, "GB/s"
             kernels.append({"kernel": k, "ms": round(ms, 5), "bound": bound, "achieved": round(ach, 3),
                             "peak": peak, "unit": unit, "frac": round(ach / peak, 5), "traffic": traffic.get(k)})
-        gate_ms = sum(ms for k, ms in avg_ms.items() if k.startswith(("gate_stage1", "gate_pf")))
+        gate_ms = sum(ms for k, ms in avg_ms.items() if k.startswith(("gate_stage1", "gate_pf"))) or 1e-9
         gate_bytes = GATE_BYTES_PER_IMAGE * B + GATE_TABLE_BYTES
+        if args.variant != "small":
+            gate_bytes = 0.0
         gate = {"kernel": "gate_path (all binarised LUT launches)", "ms": round(gate_ms, 5), "bound": "hbm",
                 "achieved": round(gate_bytes / (gate_ms * 1e-3) / 1e9, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(gate_bytes / (gate_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "traffic": None}
@@ -211,7 +218,7 @@ def main():
         roofline["kernel"] = dom["kernel"]
         roofline["ms"] = dom["ms"]
         out = {
-            "metric": "images/sec ImageNet 224x224, TT-small, MI355X; top-1 exact-match",
+            "metric": f"images/sec ImageNet 224x224, TT-{args.variant}, MI355X; top-1 exact-match",
             "value": round(n_total * args.steps / elapsed, 2),
             "unit": "images/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -219,8 +226,9 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u16/u64 packed bits + f32",
             "data": "synthetic",
-            "config": {"workload": f"TT_general_imagenet_v2_small forward, batch={B} 224x224 per GPU, "
-                                   f"bit-packed HIP LUT kernels (BASELINE.json configs[1])",
+            "config": {"workload": (f"TT_general_imagenet_v2_small forward, batch={B} 224x224 per GPU, "
+                                    f"bit-packed HIP LUT kernels (BASELINE.json configs[1])") if args.variant == "small"
+                       else f"TT {args.variant} variant forward, batch={B} 224x224 per GPU (parity-test configuration)",
                        "batch_per_gpu": B, "global_batch": n_total,
                        "parallelism": f"batch shard x{world}" + (" + RCCL all-gather of logits" if world > 1 else "")},
             "roofline": roofline,

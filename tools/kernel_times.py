@@ -1,8 +1,10 @@
 """Print per-kernel device times of the forward at a few batch sizes (GPU box)."""
 import sys, os, json, subprocess
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+variant = os.environ.get("VARIANT", "small")
 for b in (sys.argv[1:] or ["256", "2048"]):
-    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--no-cpu-baseline", "--batch", b, "--steps", "20"],
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--no-cpu-baseline", "--batch", b, "--steps", "20",
+                          "--variant", variant],
                          capture_output=True, text=True)
     try:
         d = json.loads(out.stdout.strip().splitlines()[-1])
