@@ -80,12 +80,18 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int G_BM = 256, G_BN = 128;                 // workgroup tile: 8 x 4 MFMA tiles of 32x32
 constexpr int G_MT = G_BM / 32, G_NT = G_BN / 32;
-constexpr int G_KS = 2;                               // k-steps (of 16) per LDS stage
+constexpr int G_KS = 1;                               // k-steps (of 16) per LDS stage
 constexpr int G_CHUNK = 1024;                         // one fragment block: 64 lanes x 16 B
-constexpr int G_STAGE = (G_MT + G_NT) * G_KS * 3 * G_CHUNK;   // 72 KiB
+constexpr int G_STAGE = (G_MT + G_NT) * G_KS * 3 * G_CHUNK;   // 36 KiB
+constexpr int G_STAGES = 4;                           // LDS ring: 3 stages in flight behind the one being read
+constexpr int G_WAVES = 8;                            // two waves per SIMD: one wave's LDS reads / waits hide behind the other's MFMAs
+constexpr int G_CHUNKS = (G_MT + G_NT) * G_KS * 3;    // 36 fragment blocks per stage
+constexpr int G_LOADS = (G_CHUNKS + G_WAVES - 1) / G_WAVES;   // direct-to-LDS loads per wave and stage (5; the
+                                                      // surplus slots load into a scratch block so every wave counts the same)
+constexpr int G_LDS = G_STAGES * G_STAGE + G_CHUNK;
 
 // Af: [mtile32][KS][3][64][8] bf16, Bf: [ntile32][KS][3][64][8] bf16, part: [splits][M][N] f32
-__global__ __launch_bounds__(256) void gemm_bf16x3_kernel(const uint8_t *__restrict__ Af, const uint8_t *__restrict__ Bf,
+__global__ __launch_bounds__(64 * G_WAVES) void gemm_bf16x3_kernel(const uint8_t *__restrict__ Af, const uint8_t *__restrict__ Bf,
                                                          float *__restrict__ part, int M, int N, int KS, int ks_per,
                                                          int n_tiles, int m_tiles, int splits) {
   extern __shared__ __align__(16) uint8_t lds[];
@@ -112,49 +118,69 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(const uint8_t *__restr
   const int mt0 = mtile * G_MT, nt0 = ntile * G_NT;
   const int ks_beg = slice * ks_per, iters = ks_per / G_KS;
 
+  // Each wave owns G_LOADS fixed chunks (operand, tile32, plane) of every stage; only the k-step
+  // advances, by one fragment block row (3 planes x 1 KiB), so the per-stage issue is an add and a
+  // direct-to-LDS load per chunk.  (One wave per SIMD: address arithmetic is not hidden.)
+  const uint8_t *chunk_src[G_LOADS];
+  int chunk_lds[G_LOADS];
+#pragma unroll
+  for (int jj = 0; jj < G_LOADS; ++jj) {
+    const int c = wave + G_WAVES * jj;
+    const bool real = c < G_CHUNKS;
+    const bool isA = c < G_MT * G_KS * 3;
+    const int cc = real ? (isA ? c : c - G_MT * G_KS * 3) : 0;
+    const int pl = cc % 3, kk = (cc / 3) % G_KS, tl = cc / (3 * G_KS);
+    chunk_src[jj] = (isA || !real ? Af : Bf) +
+                    ((((size_t)((isA || !real ? mt0 : nt0) + tl) * KS + ks_beg + kk) * 3 + pl) * 64 + lane) * 16;
+    chunk_lds[jj] = real ? c * G_CHUNK : -1;
+  }
   auto issue = [&](int it, int buf) {
-    // 72 chunks: A (mt, kk, pl) then B (nt, kk, pl); wave w takes chunks w, w+4, ...
-    const int ks0 = ks_beg + it * G_KS;
-    for (int c = wave; c < (G_MT + G_NT) * G_KS * 3; c += 4) {
-      const bool isA = c < G_MT * G_KS * 3;
-      const int cc = isA ? c : c - G_MT * G_KS * 3;
-      const int pl = cc % 3, kk = (cc / 3) % G_KS, tl = cc / (3 * G_KS);
-      const uint8_t *src = (isA ? Af : Bf) +
-                           ((((size_t)((isA ? mt0 : nt0) + tl) * KS + ks0 + kk) * 3 + pl) * 64 + lane) * 16;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
-                                       (__attribute__((address_space(3))) void *)(lds + buf * G_STAGE + c * G_CHUNK), 16, 0, 0);
-    }
+#pragma unroll
+    for (int jj = 0; jj < G_LOADS; ++jj)
+      __builtin_amdgcn_global_load_lds(
+          (const __attribute__((address_space(1))) void *)(chunk_src[jj] + (size_t)it * (G_KS * 3 * G_CHUNK)),
+          (__attribute__((address_space(3))) void *)(lds + (chunk_lds[jj] >= 0 ? buf * G_STAGE + chunk_lds[jj] : G_STAGES * G_STAGE)),
+          16, 0, 0);
   };
 
-  f32x16 acc[2][G_NT];
+  constexpr int MPW = G_MT / G_WAVES;                   // M-tiles per wave (1)
+  f32x16 acc[MPW][G_NT];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < MPW; ++i)
 #pragma unroll
     for (int j = 0; j < G_NT; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  issue(0, 0);
+  // Software pipeline.  The loop is latency bound with one stage in flight (an HBM round trip
+  // is longer than a stage of MFMAs), so G_STAGES-1 stages are kept in flight: a counted
+  // s_waitcnt retires the oldest, a raw s_barrier (no vmcnt(0) drain, unlike __syncthreads with
+  // LDS-DMA pending) publishes it, and the slot read in the previous iteration is refilled.
+  for (int p = 0; p < G_STAGES - 1 && p < iters; ++p) issue(p, p);
   for (int it = 0; it < iters; ++it) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();                                   // stage it&1 landed; everyone left stage (it+1)&1
-    if (it + 1 < iters) issue(it + 1, (it + 1) & 1);
-    const uint8_t *st = lds + (it & 1) * G_STAGE;
+    const int younger = min(G_STAGES - 2, iters - 1 - it);       // stages issued after stage `it`
+    if (younger >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * G_LOADS) : "memory");
+    else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G_LOADS) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                      // stage `it` landed for every wave; slot (it-1)%S is free
+    if (it + G_STAGES - 1 < iters) issue(it + G_STAGES - 1, (it + G_STAGES - 1) % G_STAGES);
+    const uint8_t *st = lds + (it % G_STAGES) * G_STAGE;
 #pragma unroll
     for (int kk = 0; kk < G_KS; ++kk) {
-      bf16x8 a[2][3], b[G_NT][3];
+      bf16x8 a[MPW][3], b[G_NT][3];
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < MPW; ++i)
 #pragma unroll
         for (int pl = 0; pl < 3; ++pl)
-          a[i][pl] = *(const bf16x8 *)(st + ((((2 * wave + i) * G_KS + kk) * 3 + pl) * G_CHUNK) + lane * 16);
+          a[i][pl] = *(const bf16x8 *)(st + ((((MPW * wave + i) * G_KS + kk) * 3 + pl) * G_CHUNK) + lane * 16);
 #pragma unroll
       for (int j = 0; j < G_NT; ++j)
 #pragma unroll
         for (int pl = 0; pl < 3; ++pl)
           b[j][pl] = *(const bf16x8 *)(st + ((G_MT * G_KS * 3 + (j * G_KS + kk) * 3 + pl) * G_CHUNK) + lane * 16);
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < MPW; ++i)
 #pragma unroll
         for (int j = 0; j < G_NT; ++j) {
           f32x16 c = acc[i][j];
@@ -171,13 +197,13 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(const uint8_t *__restr
   // C/D layout: col = lane&31 (N), row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) (M)
   float *dst = part + (size_t)slice * M * N;
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < MPW; ++i)
 #pragma unroll
     for (int j = 0; j < G_NT; ++j) {
       const int col = (nt0 + j) * 32 + (lane & 31);
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int row = (mt0 + 2 * wave + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        const int row = (mt0 + MPW * wave + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
         if (row < M && col < N) dst[(size_t)row * N + col] = acc[i][j][r];
       }
     }
@@ -283,9 +309,9 @@ int launch_gemm_bf16x3(const void *Af, const void *Bf, float *part, int M, int N
     set_error("gemm_bf16x3: K=%d not divisible into %d slices of %d k-steps", K, splits, G_KS);
     return TTNET_E_UNSUPPORTED;
   }
-  TT_HIP(hipFuncSetAttribute((const void *)gemm_bf16x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * G_STAGE));
+  TT_HIP(hipFuncSetAttribute((const void *)gemm_bf16x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, G_LDS));
   const int n_tiles = (N + G_BN - 1) / G_BN, m_tiles = (M + G_BM - 1) / G_BM;
-  hipLaunchKernelGGL(gemm_bf16x3_kernel, dim3(n_tiles * m_tiles * splits), dim3(256), 2 * G_STAGE, s, (const uint8_t *)Af,
+  hipLaunchKernelGGL(gemm_bf16x3_kernel, dim3(n_tiles * m_tiles * splits), dim3(64 * G_WAVES), G_LDS, s, (const uint8_t *)Af,
                      (const uint8_t *)Bf, part, M, N, KS, KS / splits, n_tiles, m_tiles, splits);
   TT_HIP(hipGetLastError());
   return TTNET_OK;
