@@ -314,13 +314,26 @@ __global__ __launch_bounds__(kGateThreads) void gate_pf_kernel(GateBlockArgs a, 
     b[0] = valid ? a.o1[pix] : 0; b[1] = valid ? a.o2[pix] : 0;
     b[2] = valid ? a.o3[pix] : 0; b[3] = valid ? a.o4[pix] : 0;
   };
-  uint32_t cur[4], nxt[4];
-  size_t pix, pix_n;
-  bool valid, valid_n;
-  load_words(wave, cur, pix, valid);
+  // The per-task work (two lookups, 16 ballots) is shorter than a global-load round trip, so
+  // the four input words are fetched PF tasks ahead (a register ring; the loop is unrolled by PF
+  // so that the ring index is static).
+  constexpr int PF = 4;
+  uint32_t ring[PF][4];
+  size_t ring_pix[PF];
+  bool ring_valid[PF];
+#pragma unroll
+  for (int d = 0; d < PF; ++d) load_words(wave + d * nwaves, ring[d], ring_pix[d], ring_valid[d]);
   wait_lds_stage();
-  for (int t = wave; t < tasks; t += nwaves) {
-    load_words(t + nwaves, nxt, pix_n, valid_n);          // prefetch the next task's words
+  for (int t0 = wave; t0 < tasks; t0 += PF * nwaves) {
+#pragma unroll
+    for (int d = 0; d < PF; ++d) {
+    const int t = t0 + d * nwaves;
+    if (t >= tasks) break;                               // wave-uniform
+    uint32_t cur[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) cur[i] = ring[d][i];
+    const bool valid = ring_valid[d];
+    load_words(t + PF * nwaves, ring[d], ring_pix[d], ring_valid[d]);      // refill this slot
     const int n = n0 + t / chunks;
     uint32_t r = 0;
     if (valid) {
@@ -343,10 +356,7 @@ __global__ __launch_bounds__(kGateThreads) void gate_pf_kernel(GateBlockArgs a, 
           out_rp[((size_t)n * Cout + 16 * j + lane) * HO + oys] = (m >> (s * LPR)) & ((1ull << LPR) - 1ull);
       }
     }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) cur[i] = nxt[i];
-    pix = pix_n;
-    valid = valid_n;
+    }
   }
 }
 

@@ -255,7 +255,8 @@ __global__ void head_mid_kernel(const float *__restrict__ part, int splits, cons
   if (i >= (size_t)M * N) return;
   const int nidx = i % N;
   double s = 0.0;
-  for (int z = 0; z < splits; ++z) s += (double)part[(size_t)z * M * N + i];
+#pragma unroll 8
+  for (int z = 0; z < splits; ++z) s += (double)part[(size_t)z * M * N + i];      // fixed order: reproducible
   const float zf = fmaf((float)s, scale[nidx], shift[nidx]);
   // 0.47 + 0.50 * x + 0.09 * x ** 2, evaluated left to right in fp32 like the reference
   const float t = __fadd_rn(0.47f, __fmul_rn(0.50f, zf));
@@ -267,6 +268,7 @@ __global__ void head_out_kernel(const float *__restrict__ part, int splits, cons
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (size_t)M * N) return;
   double s = 0.0;
+#pragma unroll 8
   for (int z = 0; z < splits; ++z) s += (double)part[(size_t)z * M * N + i];
   out[i] = (float)(s + (double)bias[i % N]);
 }
