@@ -141,7 +141,7 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     assert torch.cuda.is_available(), "bench.py needs a HIP device (the product has no CPU path)"
-    dev = torch.device("cuda", local_rank)
+    dev = torch.device("cuda", local_rank % torch.cuda.device_count())   # (% only matters for the 1-GPU gloo rehearsal)
     torch.cuda.set_device(dev)
 
     vargs = dict(nfilter=6, tfilter=10) if args.variant == "full" else dict(nfilter=8, tfilter=8)
@@ -176,7 +176,8 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        gloo = dist.get_backend() == "gloo"
+        t = torch.tensor([elapsed], device="cpu" if gloo else dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 

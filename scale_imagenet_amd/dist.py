@@ -32,6 +32,7 @@ def init_from_env(backend: Optional[str] = None) -> Tuple[int, int, int]:
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    backend = os.environ.get("TTNET_DIST_BACKEND", backend)     # rehearsal on one GPU: "gloo"
     if world > 1 and not dist.is_initialized():
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
@@ -62,8 +63,13 @@ def all_gather_logits(local: torch.Tensor, n_total: int, group=None) -> torch.Te
     if count < width:
         pad = torch.zeros((width - count, local.shape[1]), dtype=local.dtype, device=local.device)
         local = torch.cat([local, pad])
-    out = torch.empty((world * width, local.shape[1]), dtype=local.dtype, device=local.device)
-    dist.all_gather_into_tensor(out, local.contiguous(), group=group)
+    if local.is_cuda and dist.get_backend(group) == "gloo":     # rehearsal path: gloo gathers on the host
+        host = torch.empty((world * width, local.shape[1]), dtype=local.dtype)
+        dist.all_gather_into_tensor(host, local.cpu().contiguous(), group=group)
+        out = host.to(local.device)
+    else:
+        out = torch.empty((world * width, local.shape[1]), dtype=local.dtype, device=local.device)
+        dist.all_gather_into_tensor(out, local.contiguous(), group=group)
     if n_total == world * width:
         return out
     rows = [out[r * width: r * width + shard_bounds(n_total, r, world)[1]] for r in range(world)]

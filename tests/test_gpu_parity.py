@@ -323,3 +323,22 @@ def test_state_change_rebuilds_tables(dev):
         m.features[9].lin2.bias.add_(1.0)
         y1 = m(x)
     assert (y1 - y0 - 1.0).abs().max().item() < 1e-5
+
+
+def test_cabi_comm_single_rank(dev):
+    """ttnet_comm_* / ttnet_allgather_logits over RCCL with a world of one (the N>1 wiring is
+    covered by the gloo tests on CPU; an 8-GPU node is the driver's to launch)."""
+    import ctypes as C
+    lib = _lib.load()
+    uid = (C.c_char * 128)()
+    _lib.check(lib.ttnet_comm_unique_id(uid))
+    comm = C.c_void_p()
+    _lib.check(lib.ttnet_comm_create(uid, 0, 1, 0, C.byref(comm)))
+    local = torch.arange(4 * 1000, device=dev, dtype=torch.float32).reshape(4, 1000)
+    out = torch.zeros_like(local)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    _lib.check(lib.ttnet_allgather_logits(comm, C.c_void_p(local.data_ptr()), 4, 1000, C.c_void_p(out.data_ptr()),
+                                          C.c_void_p(stream)))
+    torch.cuda.synchronize()
+    assert torch.equal(out, local)
+    lib.ttnet_comm_destroy(comm)
