@@ -342,3 +342,33 @@ def test_cabi_comm_single_rank(dev):
     torch.cuda.synchronize()
     assert torch.equal(out, local)
     lib.ttnet_comm_destroy(comm)
+
+
+@pytest.mark.parametrize("layers", [0, 2])
+def test_other_depths_against_the_oracle(dev, layers):
+    """--layers 0 / 2 (two and four stride-2 blocks, TT_general_imagenet_v2_small.py:172-177):
+    no golden capture exists for these depths, so the HIP path is checked against the pinned
+    oracle on the same synthetic weights: gate bits from the oracle's stem bits must be
+    identical (tables are float64 on both sides), logits within 1e-5 of the exact head."""
+    from argparse import Namespace
+    from scale_imagenet_amd.spec import make_spec
+    spec = make_spec("small", 8, 8, layers)
+    st = synth.synth_state_dict(spec, calibrated=False)
+    m = ttnet.TT_vf_19lv3_imgnet_small(Namespace(nfilter=8, tfilter=8, layers=layers, groups=[1, None, 4, None]))
+    m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in st.items()}, strict=True)
+    m = m.to(dev).eval().reserve(4)
+    x = synth.synth_images(3)
+    with torch.no_grad():
+        y = m(torch.from_numpy(x).to(dev)).cpu().numpy()
+    stem_rows = m.read_stage("features.3", 3)
+    bits = OB.unpack_rows(stem_rows, 56)
+    luts = {b.name: m.get_table(b.name) for b in spec.block_tts()}
+    bt = {}
+    ref = OB.forward_from_stem_bits(bits, st, spec, luts, bt)
+    for stage, want in bt.items():
+        if stage == "flatten" or stage == spec.blocks[-1].name:
+            continue
+        assert np.array_equal(m.read_stage(stage, 3), OB.pack_rows(want)), (layers, stage)
+    assert y.shape == (3, 1000)
+    scale = max(1.0, float(np.abs(ref).max()))
+    assert np.abs(y - ref).max() <= 1e-5 * scale, (layers, np.abs(y - ref).max(), scale)
