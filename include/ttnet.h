@@ -50,7 +50,9 @@ typedef enum ttnet_dtype { TTNET_F32 = 0, TTNET_I64 = 1, TTNET_U8 = 2, TTNET_U16
 typedef enum ttnet_variant {
   TTNET_SMALL = 0,   /* models/TT_general_imagenet_v2_small.py:151  TT_vf_19lv3_imgnet_small  */
   TTNET_XSMALL = 1,  /* models/TT_general_imagenet_v2_xsmall.py:151 TT_vf_19lv3_imgnet_xsmall */
-  TTNET_FULL = 2     /* models/TT_general_imagenet_v2.py:139        TT_vf_19lv3_imgnet        */
+  TTNET_FULL = 2,    /* models/TT_general_imagenet_v2.py:139        TT_vf_19lv3_imgnet        */
+  TTNET_VALEXNET = 3 /* models/TT_FHE_XSMALL_vAlexnet.py:585        TT_FHE_XSMALL_vAlexnet (CIFAR 32x32;
+                        nfilter / tfilter / layers are ignored, as the reference's constructor ignores them) */
 } ttnet_variant;
 
 /* The constructor arguments of the reference model (args.nfilter / tfilter / layers,
@@ -92,7 +94,7 @@ int ttnet_plan_finalize(ttnet_plan *plan, void *stream);
 /* Replaces SeqBinModelHelper.forward (models/model_utils/netbin.py:703-708), i.e.
  * `outputs = model(inputs)` at main.py:261 in eval mode under no_grad.
  *   x_dev      float32 [n,3,image_h,image_w] NCHW, contiguous, on the plan's device
- *   logits_dev float32 [n,1000]
+ *   logits_dev float32 [n,n_classes]  (1000; 10 for TTNET_VALEXNET)
  * Asynchronous on `stream`. */
 int ttnet_forward(ttnet_plan *plan, const float *x_dev, int64_t n, float *logits_dev, void *stream);
 

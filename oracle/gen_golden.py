@@ -80,6 +80,112 @@ def import_reference(variant: str):
     return m
 
 
+def gen_valexnet():
+    """Config 5: TT_FHE_XSMALL_vAlexnet (CIFAR 32x32).  The reference constructor fetches
+    pretrained VGG16 / DenseNet weights (models/TT_FHE_XSMALL_vAlexnet.py:594-597); there is no
+    network here, so ``torchvision.models`` is a LOCAL un-pretrained stand-in that only
+    reproduces the ``features[0:2]`` topology (Conv2d(3,64,3,padding=1) with bias, ReLU) --
+    the stem weights then come from the synthetic state_dict like every other tensor."""
+    import torch.nn as nn
+    from scale_imagenet_amd.spec import VAlexSpec, valexnet_layout
+    for name in ("torchvision", "torchvision.transforms", "torchvision.utils", "torchvision.datasets",
+                 "torchvision.models"):
+        sys.modules.setdefault(name, types.ModuleType(name))
+    tv = sys.modules["torchvision"]
+    tv.transforms, tv.utils = sys.modules["torchvision.transforms"], sys.modules["torchvision.utils"]
+    tv.datasets, tv.models = sys.modules["torchvision.datasets"], sys.modules["torchvision.models"]
+    sys.modules["torchvision.transforms"].Normalize = object
+
+    class _VGGStandIn(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.features = nn.Sequential(nn.Conv2d(3, 64, 3, padding=1), nn.ReLU(inplace=True))
+    tv.models.vgg16 = lambda pretrained=False: _VGGStandIn()
+    tv.models.densenet121 = lambda pretrained=False: None
+    if REF not in sys.path:
+        sys.path.insert(0, REF)
+    from argparse import Namespace
+    with contextlib.redirect_stdout(io.StringIO()):
+        from models.TT_FHE_XSMALL_vAlexnet import TT_FHE_XSMALL_vAlexnet
+        m = TT_FHE_XSMALL_vAlexnet(Namespace(nfilter=8, tfilter=8, layers=1, groups=[1, None, 4, None])).eval()
+    spec = VAlexSpec()
+    layout = valexnet_layout(spec)
+    ref_sd = m.state_dict()
+    assert list(ref_sd.keys()) == list(layout.keys())
+    for k, v in ref_sd.items():
+        assert tuple(v.shape) == layout[k][0] and str(v.dtype) == "torch." + layout[k][1], k
+    with open(os.path.join(GOLD, "state_layout_valexnet.json"), "w") as f:
+        json.dump({"variant": "valexnet", "n_params": int(sum(p.numel() for p in m.parameters())),
+                   "keys": [[k, list(v.shape), str(v.dtype).replace("torch.", "")] for k, v in ref_sd.items()]},
+                  f, indent=0)
+    # calibrate the head BatchNorm1d on 64 synthetic images
+    st0 = synth.synth_state_dict(spec, calibrated=False)
+    sd0 = OF.to_torch_state(st0)
+    xc = torch.from_numpy(synth.synth_images(CALIB_IMAGES, first=CALIB_FIRST, hw=(32, 32)))
+    tp = {}
+    OF.forward_valexnet(xc, sd0, spec, tp)
+    z = tp["features.5"].reshape(CALIB_IMAGES, -1).double() @ sd0["features.7.lin1.weight"].double().t()
+    os.makedirs(DATA, exist_ok=True)
+    np.savez(os.path.join(DATA, "synth_head_bn_valexnet.npz"), running_mean=z.mean(0).float().numpy(),
+             running_var=z.var(0, unbiased=False).float().numpy())
+    st = synth.synth_state_dict(spec)
+    sd = OF.to_torch_state(st)
+    m.load_state_dict(sd, strict=True)
+    n = 16
+    x = torch.from_numpy(synth.synth_images(n, hw=(32, 32)))
+    ref_taps = {}
+    hooks = [m.features[3].register_forward_hook(lambda mod, i, o: ref_taps.__setitem__("stem.pre", o.detach().clone())),
+             m.features[4].register_forward_hook(lambda mod, i, o: ref_taps.__setitem__("features.4", o.detach().clone())),
+             m.features[5].register_forward_hook(lambda mod, i, o: ref_taps.__setitem__("features.5", o.detach().clone()))]
+    with torch.no_grad():
+        y_ref = m(x)
+    for h in hooks:
+        h.remove()
+    taps = {}
+    y = OF.forward_valexnet(x, sd, spec, taps)
+    assert torch.equal(y, y_ref), "valexnet: oracle logits differ from the reference"
+    for k in ("stem.pre", "features.4", "features.5"):
+        assert torch.equal(taps[k], ref_taps[k]), k
+    print(f"[valexnet] oracle/ttnet_float.py == reference on {n} images (all stages, bit for bit)")
+    tgt = torch.from_numpy(synth.synth_targets(n, n_classes=10))
+    out = {"logits": y_ref.numpy(), "argmax": y_ref.argmax(1).numpy(), "n_images": np.int64(n),
+           "loss": np.float64(torch.nn.functional.cross_entropy(y_ref, tgt).item())}
+    stages = {}
+    for k in ("features.4", "features.5"):
+        rows = OB.pack_rows(taps[k].numpy().astype(np.uint8))
+        stages[k] = {"shape": list(taps[k].shape), "rows_sha256": sha(rows),
+                     "per_image_sha256": [sha(rows[i]) for i in range(n)]}
+        out["rows:" + k] = rows[:DUMP_IMAGES]
+    pre = ref_taps["stem.pre"].numpy()
+    near = np.argwhere(np.abs(pre) < OB.NEAR_TIE)
+    out["stem_near_tie_idx"] = near.astype(np.int32)
+    np.savez_compressed(os.path.join(GOLD, "ref_valexnet.npz"), **out)
+    luts = {}
+    for b, modname in ((spec.conv1, "Block_conv1"), (spec.conv2, "Block_conv2"), (spec.conv3, "Block_conv3")):
+        mod = getattr(m.features[5], modname)
+        with contextlib.redirect_stdout(io.StringIO()), torch.no_grad():
+            pats = torch.from_numpy(OB.enumerate_patterns(b.fan_in_bits).astype(np.float32))
+            xin = pats.reshape(-1, b.cin_g, b.kh, b.kw).repeat(1, b.groups, 1, 1)
+            if b.padding:      # feed the pattern as the padded window: crop the centre of the padded output
+                res = mod.forward(xin, compute_final_mask_noise=False).numpy()
+                res = res[:, :, b.padding * 1, b.padding * 1] if res.shape[-1] > 1 else res
+            else:
+                res = mod.forward(xin, compute_final_mask_noise=False).numpy()
+        res = res.reshape(res.shape[0], b.groups, b.cout_g).transpose(1, 0, 2).astype(np.uint8)
+        mine, near_tab = OB.build_lut(st, b)
+        diff = np.argwhere(res != mine)
+        assert near_tab[tuple(diff.T)].all(), f"{b.name}: table mismatch outside the near-tie set"
+        luts[b.name] = {"kind": "bits", "shape": list(res.shape),
+                        "ref_sha256": sha(np.packbits(res, axis=1, bitorder="little")),
+                        "f64_sha256": sha(np.packbits(mine, axis=1, bitorder="little")),
+                        "near_ties": int(near_tab.sum()), "ref_differs_from_f64_at": diff.tolist()}
+        print(f"[valexnet] {b.name}: flips vs f64: {len(diff)}")
+    with open(os.path.join(GOLD, "ref_luts_valexnet.json"), "w") as f:
+        json.dump({"variant": "valexnet", "stages": stages, "luts": luts, "near_tie_threshold": OB.NEAR_TIE,
+                   "torch": torch.__version__, "batch": n}, f, indent=0)
+    print(f"[valexnet] logits range [{y_ref.min().item():.3f}, {y_ref.max().item():.3f}] argmax {y_ref.argmax(1).tolist()}")
+
+
 def sha(a: np.ndarray) -> str:
     return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
 
@@ -137,6 +243,9 @@ def main(variants):
     os.makedirs(GOLD, exist_ok=True)
     torch.set_num_threads(8)
     for variant in variants:
+        if variant == "valexnet":
+            gen_valexnet()
+            continue
         spec = make_spec(variant, **VARIANT_ARGS[variant])
         layout = state_dict_layout(spec)
         m = import_reference(variant)
@@ -250,4 +359,4 @@ def main(variants):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1:] or ["small", "xsmall", "full"])
+    main(sys.argv[1:] or ["small", "xsmall", "full", "valexnet"])

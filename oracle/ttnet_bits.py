@@ -194,6 +194,20 @@ def head64(feat: np.ndarray, sd: Dict[str, np.ndarray], head: str) -> np.ndarray
     return z @ sd[f"{head}.lin2.weight"].astype(np.float64).T + sd[f"{head}.lin2.bias"].astype(np.float64)
 
 
+def valexnet_from_stem_bits(bits: np.ndarray, sd: Dict[str, np.ndarray], spec, luts) -> Tuple[np.ndarray, np.ndarray]:
+    """vAlexnet (models/TT_FHE_XSMALL_vAlexnet.py:490-583, :663-675) from the binarised stem
+    output [N,64,10,10]: the concatenated block output bits [N,256,11,11] and float64 logits."""
+    out3 = apply_lut(bits, luts[spec.conv3.name], spec.conv3)
+    out2 = apply_lut(bits, luts[spec.conv2.name], spec.conv2)
+    out1 = apply_lut(bits, luts[spec.conv1.name], spec.conv1)
+    p1, p2, p34 = spec.pads
+    y = np.concatenate((_zpad(out1, p1), _zpad(out2, p2), _zpad(out3, p34), _zpad(bits, p34)), axis=1)
+    z = y.reshape(y.shape[0], -1).astype(np.float64) @ sd["features.7.lin1.weight"].astype(np.float64).T
+    s, t = fold_bn(sd, "features.7.BN2")
+    z = z * s + t
+    return y, z @ sd["features.7.lin2.weight"].astype(np.float64).T + sd["features.7.lin2.bias"].astype(np.float64)
+
+
 def forward_from_stem_bits(bits: np.ndarray, sd: Dict[str, np.ndarray], spec: VariantSpec, luts,
                            taps: Optional[Dict[str, np.ndarray]] = None, near=None) -> np.ndarray:
     """Gate path + float tail from the binarised stem output. Returns float64 logits.

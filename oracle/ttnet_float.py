@@ -139,6 +139,37 @@ def forward(x: torch.Tensor, sd: Dict[str, torch.Tensor], spec: VariantSpec,
     return classifier_scale(x, sd, head)
 
 
+@torch.no_grad()
+def forward_valexnet(x: torch.Tensor, sd: Dict[str, torch.Tensor], spec,
+                     taps: Optional[Dict[str, torch.Tensor]] = None) -> torch.Tensor:
+    """TT_FHE_XSMALL_vAlexnet eval forward (models/TT_FHE_XSMALL_vAlexnet.py): features =
+    [VGG conv3x3+bias, ReLU, BatchNorm2d, MaxPool2d(3), thresholded act (:606-614), the stride-1
+    block (:490-583), Flatten, Classifier_scale without polynomial (:663-675)]."""
+    h = F.relu(F.conv2d(x, sd["features.0.weight"], sd["features.0.bias"], 1, 1))
+    h = _bn(h, sd, "features.2")
+    h = F.max_pool2d(h, 3)
+    if taps is not None:
+        taps["stem.pre"] = h
+    h = binarize01_thresholded(h, 0.0)
+    if taps is not None:
+        taps["features.4"] = h
+    out3 = block_tt(h, sd, spec.conv3)                                          # :497
+    out2 = block_tt(h, sd, spec.conv2)                                          # :498
+    out1 = block_tt(h, sd, spec.conv1)                                          # :499
+    out4 = h                                                                    # stride 1: :505
+    assert h.shape[-1] == 10, "only the 32x32 geometry (W = 10 rule, :544-550) is restated"
+    p1, p2, p34 = spec.pads
+    out1, out2, out3, out4 = F.pad(out1, p1), F.pad(out2, p2), F.pad(out3, p34), F.pad(out4, p34)
+    outf = torch.cat((out1, out2, out3, out4), dim=1)                           # :575 (no interleave, no convf)
+    if taps is not None:
+        taps["features.5"] = outf
+    z = outf.reshape(outf.size(0), -1)
+    z = F.linear(z, sd["features.7.lin1.weight"])
+    z = F.batch_norm(z, sd["features.7.BN2.running_mean"], sd["features.7.BN2.running_var"],
+                     sd["features.7.BN2.weight"], sd["features.7.BN2.bias"], False, 0.1, BN_EPS)
+    return F.linear(z, sd["features.7.lin2.weight"], sd["features.7.lin2.bias"])
+
+
 def to_torch_state(np_state) -> Dict[str, torch.Tensor]:
     return {k: torch.from_numpy(v.copy()) for k, v in np_state.items()}
 

@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libttnet.so")
 
 TTNET_F32, TTNET_I64, TTNET_U8, TTNET_U16, TTNET_U64 = 0, 1, 2, 3, 4
-VARIANTS = {"small": 0, "xsmall": 1, "full": 2}
+VARIANTS = {"small": 0, "xsmall": 1, "full": 2, "valexnet": 3}
 
 
 class NetDesc(C.Structure):

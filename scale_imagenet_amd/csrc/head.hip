@@ -250,7 +250,7 @@ __global__ void frag_to_ref_kernel(const uint16_t *__restrict__ af, float *__res
 }
 
 __global__ void head_mid_kernel(const float *__restrict__ part, int splits, const float *__restrict__ scale,
-                                const float *__restrict__ shift, float *__restrict__ out, int M, int N) {
+                                const float *__restrict__ shift, float *__restrict__ out, int M, int N, int polynomial) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (size_t)M * N) return;
   const int nidx = i % N;
@@ -258,6 +258,10 @@ __global__ void head_mid_kernel(const float *__restrict__ part, int splits, cons
 #pragma unroll 8
   for (int z = 0; z < splits; ++z) s += (double)part[(size_t)z * M * N + i];      // fixed order: reproducible
   const float zf = fmaf((float)s, scale[nidx], shift[nidx]);
+  if (!polynomial) {                     // vAlexnet's Classifier_scale has no activation (:671-675)
+    out[i] = zf;
+    return;
+  }
   // 0.47 + 0.50 * x + 0.09 * x ** 2, evaluated left to right in fp32 like the reference
   const float t = __fadd_rn(0.47f, __fmul_rn(0.50f, zf));
   out[i] = __fadd_rn(t, __fmul_rn(0.09f, __fmul_rn(zf, zf)));
@@ -301,7 +305,7 @@ int launch_gemm_nt_splitk(const float *A, const float *B, float *part, int M, in
 int gemm_bf16x3_splits(int M, int N, int KS) {
   const int tiles = ((M + G_BM - 1) / G_BM) * ((N + G_BN - 1) / G_BN);
   int s = 1;
-  while (s * 2 * tiles <= 256 && (KS / (s * 2)) % G_KS == 0 && KS / (s * 2) >= 8) s *= 2;
+  while (s * 2 * tiles <= 256 && KS % (s * 2) == 0 && (KS / (s * 2)) % G_KS == 0 && KS / (s * 2) >= 8) s *= 2;
   return s;
 }
 
@@ -337,10 +341,10 @@ int launch_frag_to_reference_order(const void *af, float *out, int n, int G, int
 }
 
 int launch_head_mid(const float *part, int splits, const float *scale, const float *shift, float *out, int M,
-                    int N, hipStream_t s) {
+                    int N, int polynomial, hipStream_t s) {
   const size_t t = (size_t)M * N;
   hipLaunchKernelGGL(head_mid_kernel, dim3((unsigned)((t + 255) / 256)), dim3(256), 0, s, part, splits, scale, shift,
-                     out, M, N);
+                     out, M, N, polynomial);
   TT_HIP(hipGetLastError());
   return TTNET_OK;
 }

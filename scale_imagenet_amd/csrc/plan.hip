@@ -97,6 +97,9 @@ struct ttnet_plan {
   bool finalized = false;
   bool xs = false;                  // x-small variant: row-packed branch tensors, gate_xs.hip kernels
   bool full = false;                // full variant (fan-in 30): direct float64 evaluation, gate_full.hip
+  bool va = false;                  // CIFAR vAlexnet variant, gate_va.hip
+  uint64_t *va_y = nullptr;         // vAlexnet: the concatenated block output [n][256][11] rows
+  float *va_scale = nullptr, *va_shift = nullptr;   // vAlexnet stem BatchNorm folded
   float *last_float = nullptr;      // full variant: relu'd output of the last block before AvgPool2d
 
   // stem
@@ -159,6 +162,15 @@ void add_bn(ttnet_plan *pl, const std::string &prefix, int c) {
   add_tensor(pl, prefix + ".num_batches_tracked", {}, TTNET_I64, false);
 }
 
+// every Block_TT of the plan (vAlexnet's block has no convf: its entry keeps an empty name)
+std::vector<BlockTT *> all_block_tts(ttnet_plan *pl) {
+  std::vector<BlockTT *> v;
+  for (auto &mh : pl->blocks)
+    for (BlockTT *b : {&mh.c1, &mh.c2, &mh.c3, &mh.cf})
+      if (!b->g.name.empty()) v.push_back(b);
+  return v;
+}
+
 void add_block_tt(ttnet_plan *pl, const BlockGeom &g) {
   const int mid = 8 * g.in_planes;
   add_tensor(pl, g.name + ".conv1.weight", {mid, g.cin_g(), g.kh, g.kw}, TTNET_F32, true);
@@ -179,8 +191,49 @@ BlockGeom make_geom(const std::string &name, int in_planes, int out_planes, int 
 // Geometry of the network (mirrors make_small_network,
 // models/TT_general_imagenet_v2_small.py:159-203, and the shape-keyed branch padding of
 // the block forward, :98-139).
+// TT_FHE_XSMALL_vAlexnet (models/TT_FHE_XSMALL_vAlexnet.py:585-660): fixed geometry
+int build_geometry_valexnet(ttnet_plan *pl) {
+  const ttnet_net_desc &d = pl->desc;
+  if (d.image_h != 32 || d.image_w != 32) {
+    set_error("vAlexnet takes 32x32 inputs (got %dx%d)", d.image_h, d.image_w);
+    return TTNET_E_UNSUPPORTED;
+  }
+  if (d.max_batch < 1) {
+    set_error("max_batch must be positive");
+    return TTNET_E_INVALID;
+  }
+  pl->va = true;
+  pl->p = 64;
+  pl->n_classes = 10; pl->inter = 100; pl->fcsize = 256 * 11 * 11;
+  pl->head = "features.7";
+  for (const char *pre : {"VGG_Model16_0", "features.0"}) {      // one conv module registered under two names
+    add_tensor(pl, std::string(pre) + ".weight", {64, 3, 3, 3}, TTNET_F32, std::string(pre) == "features.0");
+    add_tensor(pl, std::string(pre) + ".bias", {64}, TTNET_F32, std::string(pre) == "features.0");
+  }
+  add_bn(pl, "features.2", 64);
+  add_tensor(pl, "features.4.grad_scale", {}, TTNET_F32, false);
+  MultiHead mh;
+  mh.name = "features.5";
+  mh.C = 64; mh.H = 10; mh.W = 10; mh.Ho = 11; mh.Wo = 11; mh.stride = 1; mh.last = true;
+  mh.c1.g = make_geom("features.5.Block_conv1", 64, 64, 3, 2, 1, 1, 64, false);
+  mh.c2.g = make_geom("features.5.Block_conv2", 64, 64, 2, 3, 1, 1, 64, false);
+  mh.c3.g = make_geom("features.5.Block_conv3", 64, 64, 1, 1, 1, 0, 8, false);
+  for (BlockTT *b : {&mh.c1, &mh.c2, &mh.c3}) {
+    add_block_tt(pl, b->g);
+    b->perm.resize(b->g.nbits());
+    for (int q = 0; q < b->g.nbits(); ++q) b->perm[q] = (uint8_t)q;
+  }
+  pl->blocks.push_back(mh);
+  add_tensor(pl, "features.7.lin1.weight", {pl->inter, pl->fcsize}, TTNET_F32, true);
+  add_bn(pl, "features.7.BN2", pl->inter);
+  add_tensor(pl, "features.7.lin2.weight", {pl->n_classes, pl->inter}, TTNET_F32, true);
+  add_tensor(pl, "features.7.lin2.bias", {pl->n_classes}, TTNET_F32, true);
+  return TTNET_OK;
+}
+
 int build_geometry(ttnet_plan *pl) {
   const ttnet_net_desc &d = pl->desc;
+  if (d.variant == TTNET_VALEXNET) return build_geometry_valexnet(pl);
   int kh = 4, kw = 4, pad = 2, gsize = 16;
   if (d.variant == TTNET_SMALL) {
   } else if (d.variant == TTNET_XSMALL) {
@@ -309,6 +362,39 @@ int allocate(ttnet_plan *pl) {
   const int nb = pl->desc.max_batch;
   size_t *ws = &pl->workspace_bytes, *tb = &pl->table_bytes;
   for (auto &kv : pl->tensors) TT_TRY(dev_alloc(pl, (uint8_t **)&kv.second.dev, kv.second.bytes, true));
+  if (pl->va) {
+    MultiHead &mh = pl->blocks[0];
+    pl->x_rp.resize(1);
+    pl->x_cp.resize(1);
+    TT_TRY(dev_alloc(pl, &pl->x_rp[0], (size_t)nb * 64 * 10, true, ws));
+    TT_TRY(dev_alloc(pl, &pl->va_y, (size_t)nb * 256 * 11, true, ws));
+    TT_TRY(dev_alloc(pl, &pl->va_scale, 64, false));
+    TT_TRY(dev_alloc(pl, &pl->va_shift, 64, false));
+    for (BlockTT *b : {&mh.c1, &mh.c2, &mh.c3}) {
+      const BlockGeom &g = b->g;
+      TT_TRY(dev_alloc(pl, (uint8_t **)&b->table, g.table_bytes(), true, tb));
+      TT_TRY(dev_alloc(pl, &b->perm_dev, b->perm.size(), false));
+      TT_HIP(hipMemcpy(b->perm_dev, b->perm.data(), b->perm.size(), hipMemcpyHostToDevice));
+      TT_TRY(dev_alloc(pl, &b->s1, (size_t)8 * g.in_planes, false));
+      TT_TRY(dev_alloc(pl, &b->t1, (size_t)8 * g.in_planes, false));
+      TT_TRY(dev_alloc(pl, &b->s2, g.out_planes, false));
+      TT_TRY(dev_alloc(pl, &b->t2, g.out_planes, false));
+      TT_TRY(dev_alloc(pl, &b->near_dev, 1, true));
+    }
+    const int nb_pad_va = (nb + 255) / 256 * 256;
+    TT_TRY(dev_alloc(pl, &pl->feat, frag_elems(nb_pad_va, pl->fcsize), true, ws));
+    TT_TRY(dev_alloc(pl, &pl->w1f, frag_elems(128, pl->fcsize), false));
+    TT_TRY(dev_alloc(pl, &pl->bn_scale, pl->inter, false));
+    TT_TRY(dev_alloc(pl, &pl->bn_shift, pl->inter, false));
+    TT_TRY(dev_alloc(pl, &pl->mid, (size_t)nb * pl->inter, true, ws));
+    size_t pe_va = 0;
+    for (int n = 1; n <= nb; ++n)
+      pe_va = std::max(pe_va, (size_t)std::max(gemm_bf16x3_splits(n, pl->inter, pl->fcsize / 16),
+                                               gemm_splits(n, pl->n_classes, pl->inter)) * n * pl->inter);
+    pl->part_elems = pe_va;
+    TT_TRY(dev_alloc(pl, &pl->part, pe_va, false, ws));
+    return TTNET_OK;
+  }
   TT_TRY(dev_alloc(pl, &pl->stem_wt, stem_split_weights_elems(), false));
   TT_TRY(dev_alloc(pl, &pl->stem_scale, pl->p, false));
   TT_TRY(dev_alloc(pl, &pl->stem_shift, pl->p, false));
@@ -503,6 +589,25 @@ int run_full_block(ttnet_plan *pl, size_t i, int n, hipStream_t s) {
   return TTNET_OK;
 }
 
+// vAlexnet: block + Flatten + Classifier_scale from the stem bits in x_rp[0]
+int run_va_tail(ttnet_plan *pl, int n, float *logits, hipStream_t s) {
+  MultiHead &mh = pl->blocks[0];
+  TT_TIMED(pl, "va.block", s, launch_va_block(pl->x_rp[0], mh.c1.table, mh.c2.table, mh.c3.table, pl->va_y, n, s));
+  TT_TIMED(pl, "va.flatten", s, launch_va_feat(pl->va_y, pl->feat, n, s));
+  const int s1 = gemm_bf16x3_splits(n, pl->inter, pl->fcsize / 16);
+  TT_TIMED(pl, "head.lin1", s, launch_gemm_bf16x3(pl->feat, pl->w1f, pl->part, n, pl->inter, pl->fcsize, s1, s));
+  TT_TIMED(pl, "head.bn", s, launch_head_mid(pl->part, s1, pl->bn_scale, pl->bn_shift, pl->mid, n, pl->inter, 0, s));
+  const int s2 = gemm_splits(n, pl->n_classes, pl->inter);
+  TT_TIMED(pl, "head.lin2", s,
+           launch_gemm_nt_splitk(pl->mid, (const float *)pl->tensors["features.7.lin2.weight"].dev, pl->part, n,
+                                 pl->n_classes, pl->inter, s2, s));
+  TT_TIMED(pl, "head.bias", s,
+           launch_head_out(pl->part, s2, (const float *)pl->tensors["features.7.lin2.bias"].dev, logits, n,
+                           pl->n_classes, s));
+  pl->last_n = n;
+  return TTNET_OK;
+}
+
 int run_from_blocks(ttnet_plan *pl, int n, float *logits, hipStream_t s) {
   for (size_t i = 0; i < pl->blocks.size(); ++i) {
     MultiHead &mh = pl->blocks[i];
@@ -532,7 +637,7 @@ int run_from_blocks(ttnet_plan *pl, int n, float *logits, hipStream_t s) {
   }
   const int s1 = gemm_bf16x3_splits(n, pl->inter, pl->fcsize / 16);
   TT_TIMED(pl, "head.lin1", s, launch_gemm_bf16x3(pl->feat, pl->w1f, pl->part, n, pl->inter, pl->fcsize, s1, s));
-  TT_TIMED(pl, "head.bn_poly", s, launch_head_mid(pl->part, s1, pl->bn_scale, pl->bn_shift, pl->mid, n, pl->inter, s));
+  TT_TIMED(pl, "head.bn_poly", s, launch_head_mid(pl->part, s1, pl->bn_scale, pl->bn_shift, pl->mid, n, pl->inter, 1, s));
   const int s2 = gemm_splits(n, pl->n_classes, pl->inter);
   TT_TIMED(pl, "head.lin2", s,
            launch_gemm_nt_splitk(pl->mid, (const float *)pl->tensors[pl->head + ".lin2.weight"].dev, pl->part, n,
@@ -561,9 +666,8 @@ int check_ready(ttnet_plan *pl, const void *in, int64_t n, const void *out) {
 }
 
 BlockTT *find_block(ttnet_plan *pl, const char *name) {
-  for (auto &mh : pl->blocks)
-    for (BlockTT *b : {&mh.c1, &mh.c2, &mh.c3, &mh.cf})
-      if (b->g.name == name) return b;
+  for (BlockTT *b : all_block_tts(pl))
+    if (b->g.name == name) return b;
   return nullptr;
 }
 
@@ -638,9 +742,8 @@ int ttnet_plan_set_tensor(ttnet_plan *pl, const char *key, const void *ptr, cons
   t.set = true;
   pl->finalized = false;
   // new parameters for a Block_TT invalidate a table injected with ttnet_plan_set_table
-  for (auto &mh : pl->blocks)
-    for (BlockTT *b : {&mh.c1, &mh.c2, &mh.c3, &mh.cf})
-      if (k.compare(0, b->g.name.size() + 1, b->g.name + ".") == 0) b->user_table = false;
+  for (BlockTT *b : all_block_tts(pl))
+    if (k.compare(0, b->g.name.size() + 1, b->g.name + ".") == 0) b->user_table = false;
   return TTNET_OK;
 }
 
@@ -657,6 +760,26 @@ int ttnet_plan_finalize(ttnet_plan *pl, void *stream) {
       set_error("missing key in state_dict: %s", k.c_str());
       return TTNET_E_STATE;
     }
+  }
+  if (pl->va) {
+    std::vector<double> sc, sh;
+    TT_TRY(fold_bn(pl, "features.2", sc, sh));
+    TT_TRY(upload_f32(pl->va_scale, sc));
+    TT_TRY(upload_f32(pl->va_shift, sh));
+    for (BlockTT *b : all_block_tts(pl)) TT_TRY(build_table(pl, *b, s));
+    TT_TRY(fold_bn(pl, "features.7.BN2", sc, sh));
+    TT_TRY(upload_f32(pl->bn_scale, sc));
+    TT_TRY(upload_f32(pl->bn_shift, sh));
+    TT_TRY(launch_split_to_frag((const float *)pl->tensors["features.7.lin1.weight"].dev, pl->w1f, pl->inter, pl->fcsize, 128, s));
+    TT_HIP(hipStreamSynchronize(s));
+    for (BlockTT *b : all_block_tts(pl)) {
+      if (b->user_table) continue;
+      unsigned v = 0;
+      TT_HIP(hipMemcpy(&v, b->near_dev, sizeof(v), hipMemcpyDeviceToHost));
+      b->near_ties = v;
+    }
+    pl->finalized = true;
+    return TTNET_OK;
   }
   // stem: weights split into three bf16 planes in MFMA fragment order; BN folded to fp32 scale/shift
   {
@@ -697,6 +820,13 @@ int ttnet_forward(ttnet_plan *pl, const float *x_dev, int64_t n, float *logits_d
   TT_TRY(check_ready(pl, x_dev, n, logits_dev));
   hipStream_t s = (hipStream_t)stream;
   pl->timing_used = 0;
+  if (pl->va) {
+    TT_TIMED(pl, "va.stem", s,
+             launch_va_stem(x_dev, (const float *)pl->tensors["features.0.weight"].dev,
+                            (const float *)pl->tensors["features.0.bias"].dev, pl->va_scale, pl->va_shift, pl->x_rp[0],
+                            (int)n, s));
+    return run_va_tail(pl, (int)n, logits_dev, s);
+  }
   TT_TIMED(pl, "stem", s,
            launch_stem(x_dev, pl->stem_wt, pl->stem_scale, pl->stem_shift, pl->x_rp[0], pl->full ? nullptr : pl->x_cp[0], (int)n,
                        pl->p, s));
@@ -710,6 +840,7 @@ int ttnet_forward_from_stem_bits(ttnet_plan *pl, const uint64_t *rows_dev, int64
   pl->timing_used = 0;
   const MultiHead &b0 = pl->blocks[0];
   TT_HIP(hipMemcpyAsync(pl->x_rp[0], rows_dev, (size_t)n * b0.C * b0.H * 8, hipMemcpyDeviceToDevice, s));
+  if (pl->va) return run_va_tail(pl, (int)n, logits_dev, s);
   if (!pl->full && !pl->xs) TT_TRY(launch_rp_to_cp(pl->x_rp[0], pl->x_cp[0], (int)n, b0.C, b0.H, b0.W, s));
   return run_from_blocks(pl, (int)n, logits_dev, s);
 }
@@ -736,6 +867,21 @@ int ttnet_read_stage(ttnet_plan *pl, const char *stage, int64_t n, void *dst, si
     TT_HIP(hipStreamSynchronize(s));
     return TTNET_OK;
   };
+  if (pl->va) {
+    if (st == "features.4") return copy_out(pl->x_rp[0], (size_t)n * 64 * 10 * 8);
+    if (st == "features.5") return copy_out(pl->va_y, (size_t)n * 256 * 11 * 8);
+    if (st == "flatten") {
+      float *tmp = nullptr;
+      const size_t elems = (size_t)n * pl->fcsize;
+      TT_HIP(hipMalloc((void **)&tmp, elems * 4));
+      int r = launch_va_frag_to_flat(pl->feat, tmp, (int)n, s);
+      if (r == TTNET_OK) r = copy_out(tmp, elems * 4);
+      (void)hipFree(tmp);
+      return r;
+    }
+    set_error("unknown stage %s", stage);
+    return TTNET_E_INVALID;
+  }
   for (size_t i = 0; i < pl->blocks.size(); ++i) {
     MultiHead &mh = pl->blocks[i];
     const std::string in_name = i == 0 ? std::string("features.3") : pl->blocks[i - 1].name;

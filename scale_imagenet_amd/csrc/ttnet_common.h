@@ -155,6 +155,12 @@ int launch_full_pw(const FullPwArgs &a, hipStream_t s);
 int launch_rp_majority(const uint64_t *x, uint64_t *out, int n, int C, int H, int W, int Ho, int pad_t, int pad_l,
                        hipStream_t s);
 int launch_full_pool_split(const float *x, void *feat_frag, int n, int C, int H, int W, hipStream_t s);
+// CIFAR vAlexnet variant (gate_va.hip)
+int launch_va_stem(const float *x, const float *w, const float *bias, const float *scale, const float *shift,
+                   uint64_t *rp, int n, hipStream_t s);
+int launch_va_block(const uint64_t *x_rp, const void *t1, const void *t2, const void *t3, uint64_t *y, int n, hipStream_t s);
+int launch_va_feat(const uint64_t *y, void *feat_frag, int n, hipStream_t s);
+int launch_va_frag_to_flat(const void *af, float *out, int n, hipStream_t s);
 int launch_cp_to_rp(const uint16_t *cp, uint64_t *rp, int n, int C, int H, int W, hipStream_t s);
 int launch_rp_to_cp(const uint64_t *rp, uint16_t *cp, int n, int C, int H, int W, hipStream_t s);
 // feature planes (fragment order) -> float32 [n][(16g+k)*PP + pp] (reference Flatten order)
@@ -171,7 +177,7 @@ int launch_gemm_nt_splitk(const float *A, const float *B, float *part, int M, in
                           hipStream_t s);
 // z = sum_s part; z = z*scale+shift; out = 0.47+0.5z+0.09z^2   (Classifier_scale middle)
 int launch_head_mid(const float *part, int splits, const float *scale, const float *shift, float *out, int M,
-                    int N, hipStream_t s);
+                    int N, int polynomial, hipStream_t s);
 // out = sum_s part + bias
 int launch_head_out(const float *part, int splits, const float *bias, float *out, int M, int N, hipStream_t s);
 // W1p[o][(g*PP+pp)*16+k] = W1[o][(16g+k)*PP+pp]

@@ -234,3 +234,57 @@ def state_dict_layout(spec: VariantSpec) -> "OrderedDict[str, Tuple[Tuple[int, .
     L[f"{head}.lin2.weight"] = ((spec.n_classes, spec.inter), "float32")
     L[f"{head}.lin2.bias"] = ((spec.n_classes,), "float32")
     return L
+
+
+# ---- CIFAR "vAlexnet" variant (models/TT_FHE_XSMALL_vAlexnet.py:434-676) ----------------------
+@dataclass(frozen=True)
+class VAlexSpec:
+    """TT_FHE_XSMALL_vAlexnet: VGG16 features[0:2] stem (Conv2d(3,64,3,pad 1)+bias, ReLU; the
+    reference fetches pretrained weights, :594-604), BatchNorm2d, MaxPool2d(3), thresholded act,
+    ONE stride-1 4-branch block with (3,2)/(2,3) windows and 8-channel 1x1 groups, plain concat
+    (no interleave, no convf, :575-583), Flatten, Classifier_scale(30976, 10, 100) (:663-675)."""
+    variant: str = "valexnet"
+    image_hw: Tuple[int, int] = (32, 32)
+    p: int = 64
+    pooled: int = 10                      # 32 // 3
+    out_hw: Tuple[int, int] = (11, 11)    # branches after the W = 10 padding rule (:544-550)
+    fcsize: int = 256 * 11 * 11
+    inter: int = 100
+    n_classes: int = 10
+    conv1: BlockTTSpec = BlockTTSpec("features.5.Block_conv1", 64, 64, 3, 2, 1, 1, 64)
+    conv2: BlockTTSpec = BlockTTSpec("features.5.Block_conv2", 64, 64, 2, 3, 1, 1, 64)
+    conv3: BlockTTSpec = BlockTTSpec("features.5.Block_conv3", 64, 64, 1, 1, 1, 0, 8)
+    # zero padding of (out1, out2, out3/out4) as (left, right, top, bottom), :544-550
+    pads: Tuple[Tuple[int, int, int, int], ...] = ((0, 0, 0, 1), (0, 1, 0, 0), (0, 1, 0, 1))
+
+    def block_tts(self) -> List[BlockTTSpec]:
+        return [self.conv1, self.conv2, self.conv3]
+
+
+def valexnet_layout(spec: "VAlexSpec" = None) -> "OrderedDict[str, Tuple[Tuple[int, ...], str]]":
+    """The 57 state_dict entries in the reference's order; the stem conv is registered twice
+    (as ``VGG_Model16_0`` and as ``features.0``), so its two tensors appear under both names."""
+    spec = spec or VAlexSpec()
+    L: "OrderedDict[str, Tuple[Tuple[int, ...], str]]" = OrderedDict()
+    for pre in ("VGG_Model16_0", "features.0"):
+        L[f"{pre}.weight"] = ((64, 3, 3, 3), "float32")
+        L[f"{pre}.bias"] = ((64,), "float32")
+
+    def bn(prefix, c):
+        for leaf in ("weight", "bias", "running_mean", "running_var"):
+            L[f"{prefix}.{leaf}"] = ((c,), "float32")
+        L[f"{prefix}.num_batches_tracked"] = ((), "int64")
+    bn("features.2", 64)
+    L["features.4.grad_scale"] = ((), "float32")
+    for b in spec.block_tts():
+        mid = T_EXPAND * b.in_planes
+        L[f"{b.name}.conv1.weight"] = ((mid, b.cin_g, b.kh, b.kw), "float32")
+        bn(f"{b.name}.bn1", mid)
+        L[f"{b.name}.conv2.weight"] = ((b.out_planes, mid // b.groups, 1, 1), "float32")
+        bn(f"{b.name}.bn2", b.out_planes)
+        L[f"{b.name}.act.grad_scale"] = ((), "float32")
+    L["features.7.lin1.weight"] = ((spec.inter, spec.fcsize), "float32")
+    bn("features.7.BN2", spec.inter)
+    L["features.7.lin2.weight"] = ((spec.n_classes, spec.inter), "float32")
+    L["features.7.lin2.bias"] = ((spec.n_classes,), "float32")
+    return L

@@ -131,8 +131,8 @@ def synth_state_dict(spec, weight_seed: int = 0, calibrated: bool = True) -> "Or
     would have left them), stored as data in ``data/synth_head_bn_<variant>.npz`` by
     oracle/gen_golden.py.  With random statistics the classifier emits one constant class
     for every image, which would make the top-1 check vacuous."""
-    from .spec import state_dict_layout
-    layout = state_dict_layout(spec)
+    from .spec import state_dict_layout, valexnet_layout
+    layout = valexnet_layout(spec) if spec.variant == "valexnet" else state_dict_layout(spec)
     out: "OrderedDict[str, np.ndarray]" = OrderedDict()
     for key, (shape, dtype) in layout.items():
         if key.endswith(".bias") and ".lin" in key:
@@ -143,13 +143,16 @@ def synth_state_dict(spec, weight_seed: int = 0, calibrated: bool = True) -> "Or
         else:
             out[key] = synth_tensor(key, shape, dtype, weight_seed)
         assert out[key].dtype == np.dtype(dtype), key
+    if spec.variant == "valexnet":          # the stem conv is one module under two names
+        out["VGG_Model16_0.weight"] = out["features.0.weight"]
+        out["VGG_Model16_0.bias"] = out["features.0.bias"]
     if calibrated:
         if weight_seed != 0:
             raise ValueError("calibrated head statistics exist for weight_seed 0 only")
         path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data",
                             f"synth_head_bn_{spec.variant}.npz")
         with np.load(path) as z:
-            head = f"features.{4 + len(spec.blocks) + 2}.BN2"
+            head = "features.7.BN2" if spec.variant == "valexnet" else f"features.{4 + len(spec.blocks) + 2}.BN2"
             for leaf in ("running_mean", "running_var"):
                 assert z[leaf].shape == out[f"{head}.{leaf}"].shape
                 out[f"{head}.{leaf}"] = z[leaf].astype(np.float32)

@@ -25,7 +25,8 @@ import torch
 import torch.nn as nn
 
 from . import _lib
-from .spec import BlockTTSpec, MultiHeadSpec, VariantSpec, make_spec, state_dict_layout
+from .spec import (BlockTTSpec, MultiHeadSpec, VAlexSpec, VariantSpec, make_spec, state_dict_layout,
+                   valexnet_layout)
 
 _DT = {torch.float32: _lib.TTNET_F32, torch.int64: _lib.TTNET_I64}
 
@@ -112,7 +113,8 @@ class _Plan:
         self.device_index = device_index
         self.max_batch = max_batch
         self.handle = C.c_void_p()
-        desc = _lib.NetDesc(_lib.VARIANTS[spec.variant], int(args.nfilter), int(args.tfilter), int(args.layers),
+        desc = _lib.NetDesc(_lib.VARIANTS[spec.variant], int(getattr(args, "nfilter", 8)),
+                            int(getattr(args, "tfilter", 8)), int(getattr(args, "layers", 1)),
                             spec.image_hw[0], spec.image_hw[1], int(max_batch), 0)
         _lib.check(lib.ttnet_plan_create(C.byref(desc), device_index, C.byref(self.handle)))
         self.signature = None
@@ -156,6 +158,9 @@ class _TTNetBase(nn.Module):
     def __init__(self, args):
         super().__init__()
         self.args = args
+        if self.VARIANT == "valexnet":
+            self._init_valexnet()
+            return
         spec = make_spec(self.VARIANT, int(args.nfilter), int(args.tfilter), int(args.layers))
         self.spec = spec
         layers = [nn.AvgPool2d(2),
@@ -177,6 +182,30 @@ class _TTNetBase(nn.Module):
         layout = state_dict_layout(spec)
         mine = self.state_dict()
         assert list(mine.keys()) == list(layout.keys()), "state_dict layout drifted from spec"
+
+    def _init_valexnet(self):
+        """State of TT_FHE_XSMALL_vAlexnet (models/TT_FHE_XSMALL_vAlexnet.py:585-660): the stem
+        conv is registered as ``VGG_Model16_0`` and again inside ``features`` (57 keys)."""
+        spec = VAlexSpec()
+        self.spec = spec
+        self.VGG_Model16_0 = nn.Conv2d(3, 64, 3, padding=1)
+        self.VGG_Model16_1 = nn.ReLU(inplace=True)
+        blk = _Holder()
+        blk.pad0 = nn.ZeroPad2d((1, 0, 1, 0))
+        blk.Block_conv1 = Block_TT(spec.conv1)
+        blk.Block_conv2 = Block_TT(spec.conv2)
+        blk.Block_conv3 = Block_TT(spec.conv3)
+        head = _Holder()
+        head.lin1 = nn.Linear(spec.fcsize, spec.inter, bias=False)
+        head.BN2 = nn.BatchNorm1d(spec.inter)
+        head.lin2 = nn.Linear(spec.inter, spec.n_classes, bias=True)
+        self.features = nn.Sequential(self.VGG_Model16_0, self.VGG_Model16_1, nn.BatchNorm2d(64), nn.MaxPool2d(3),
+                                      Binarize01Act(T=0.0), blk, Flatten(), head)
+        for mod in self.modules():
+            if isinstance(mod, (nn.BatchNorm2d, nn.BatchNorm1d)):
+                mod.num_batches_tracked.fill_(1)
+        self._plans = {}
+        assert list(self.state_dict().keys()) == list(valexnet_layout(spec).keys()), "state_dict layout drifted"
 
     # -- plan management ------------------------------------------------------------------
     def _state_signature(self):
@@ -255,6 +284,8 @@ class _TTNetBase(nn.Module):
         return out
 
     def _stage_shape(self, stage: str):
+        if self.VARIANT == "valexnet":
+            return {"features.4": (64, 10), "features.5": (256, 11)}[stage]
         if stage == "features.3":
             return self.spec.p, 56
         for b in self.spec.blocks:
@@ -316,3 +347,10 @@ class TT_vf_19lv3_imgnet_xsmall(_TTNetBase):
 
 class TT_vf_19lv3_imgnet(_TTNetBase):
     VARIANT = "full"
+
+
+class TT_FHE_XSMALL_vAlexnet(_TTNetBase):
+    """models/TT_FHE_XSMALL_vAlexnet.py:585 (CIFAR 32x32, 10 classes).  Unlike the reference it
+    does not fetch pretrained VGG16 weights: the stem conv is an ordinary parameter, loaded from
+    the checkpoint like the rest."""
+    VARIANT = "valexnet"

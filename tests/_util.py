@@ -22,7 +22,7 @@ def sha(a: np.ndarray) -> str:
 
 
 def args_for(variant: str) -> Namespace:
-    return Namespace(groups=[1, None, 4, None], **VARIANT_ARGS[variant])
+    return Namespace(groups=[1, None, 4, None], **VARIANT_ARGS.get(variant, VARIANT_ARGS["small"]))
 
 
 @lru_cache(maxsize=None)
@@ -45,7 +45,7 @@ def golden_layout(variant: str):
 
 @lru_cache(maxsize=None)
 def spec_and_state(variant: str):
-    from scale_imagenet_amd.spec import make_spec
+    from scale_imagenet_amd.spec import VAlexSpec, make_spec
     from scale_imagenet_amd.synth import synth_state_dict
-    spec = make_spec(variant, **VARIANT_ARGS[variant])
+    spec = VAlexSpec() if variant == "valexnet" else make_spec(variant, **VARIANT_ARGS[variant])
     return spec, synth_state_dict(spec)

@@ -372,3 +372,46 @@ def test_other_depths_against_the_oracle(dev, layers):
     assert y.shape == (3, 1000)
     scale = max(1.0, float(np.abs(ref).max()))
     assert np.abs(y - ref).max() <= 1e-5 * scale, (layers, np.abs(y - ref).max(), scale)
+
+
+def test_valexnet_config5(dev):
+    """BASELINE config 5: TT_FHE_XSMALL_vAlexnet, CIFAR 32x32 (non-square 3x2 / 2x3 windows at
+    stride 1, 8-channel 1x1 groups, no convf).  The stem weights are synthetic like the rest: the
+    reference's pretrained-VGG fetch is unavailable offline (gen_golden.py uses a local stand-in)."""
+    g, j = golden_npz("valexnet"), golden_json("valexnet")
+    spec, st = spec_and_state("valexnet")
+    n = int(g["n_images"])
+    m = ttnet.TT_FHE_XSMALL_vAlexnet(args_for("valexnet"))
+    m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in st.items()}, strict=True)
+    m = m.to(dev).eval().reserve(256)
+    x = synth.synth_images(n, hw=(32, 32))
+    with torch.no_grad():
+        y = m(torch.from_numpy(x).to(dev)).cpu().numpy()
+    assert y.shape == (n, 10)
+    # tables: GPU float64 == numpy float64 == the reference's own float32 module (no near-tie flips)
+    for b in spec.block_tts():
+        tab = m.get_table(b.name)
+        assert sha(np.packbits(tab, axis=1, bitorder="little")) == j["luts"][b.name]["f64_sha256"], b.name
+        assert j["luts"][b.name]["f64_sha256"] == j["luts"][b.name]["ref_sha256"]
+    # stem bits: equal to the reference except at near ties of the float stem
+    taps = {}
+    y_ref = OF.forward_valexnet(torch.from_numpy(x), OF.to_torch_state(st), spec, taps).numpy()
+    stem = OB.unpack_rows(m.read_stage("features.4", n), 10)
+    d = np.argwhere(stem != taps["features.4"].numpy().astype(np.uint8))
+    pre = taps["stem.pre"].numpy()
+    assert all(abs(pre[tuple(i)]) < OB.NEAR_TIE for i in d)
+    # block + head from the reference's stem bits: every stage hash, logits vs the exact head
+    rows = OB.pack_rows(taps["features.4"].numpy().astype(np.uint8))
+    with torch.no_grad():
+        y2 = m.forward_from_stem_bits(torch.from_numpy(rows.view(np.int64)).to(dev)).cpu().numpy()
+    got = m.read_stage("features.5", n)
+    assert [sha(got[i]) for i in range(n)] == j["stages"]["features.5"]["per_image_sha256"]
+    luts = {b.name: m.get_table(b.name) for b in spec.block_tts()}
+    _, exact = OB.valexnet_from_stem_bits(taps["features.4"].numpy().astype(np.uint8), st, spec, luts)
+    ref_dev = float(np.abs(g["logits"] - exact).max())
+    assert np.abs(y2 - exact).max() <= LOGIT_TOL
+    assert np.abs(y2 - g["logits"]).max() <= LOGIT_TOL + ref_dev
+    assert np.array_equal(y2.argmax(1), g["argmax"])
+    if len(d) == 0:
+        assert np.abs(y - y2).max() == 0.0
+    assert np.array_equal(m.read_stage("flatten", 2)[0], taps["features.5"].numpy().reshape(n, -1)[0])

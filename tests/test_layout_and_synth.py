@@ -93,3 +93,18 @@ def test_synth_shards_are_consistent():
     b = np.concatenate([synth.synth_images_u8(3, first=0), synth.synth_images_u8(3, first=3)])
     assert np.array_equal(a, b)
     assert synth.synth_targets(4, first=998).tolist() == [998, 999, 0, 1]
+
+
+def test_valexnet_layout_and_module():
+    from scale_imagenet_amd import ttnet
+    from scale_imagenet_amd.spec import valexnet_layout
+    g = golden_layout("valexnet")
+    layout = valexnet_layout()
+    assert [k for k, _, _ in g["keys"]] == list(layout.keys()) and len(layout) == 57
+    m = ttnet.TT_FHE_XSMALL_vAlexnet(args_for("valexnet"))
+    sd = m.state_dict()
+    assert [k for k, _, _ in g["keys"]] == list(sd.keys())
+    assert sum(p.numel() for p in m.parameters()) == g["n_params"]
+    spec, st = spec_and_state("valexnet")
+    m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in st.items()}, strict=True)
+    assert m.VGG_Model16_0.weight is m.features[0].weight

@@ -102,3 +102,24 @@ def test_pack_roundtrip():
     b = rng.integers(0, 2, size=(2, 32, 5, 29), dtype=np.uint8)
     assert np.array_equal(OB.unpack_rows(OB.pack_rows(b), 29), b)
     assert np.array_equal(OB.unpack_channels(OB.pack_channels(b), 32), b)
+
+
+def test_valexnet_oracles_reproduce_reference():
+    """Config 5 (CIFAR vAlexnet): float oracle == reference capture; bit oracle (float64 tables)
+    reproduces every reference stage from the reference's stem bits."""
+    g, j = golden_npz("valexnet"), golden_json("valexnet")
+    spec, st = spec_and_state("valexnet")
+    n = int(g["n_images"])
+    taps = {}
+    y = OF.forward_valexnet(torch.from_numpy(synth.synth_images(n, hw=(32, 32))), OF.to_torch_state(st), spec, taps)
+    assert np.abs(y.numpy() - g["logits"]).max() <= 1e-5 and np.array_equal(y.argmax(1).numpy(), g["argmax"])
+    for k, info in j["stages"].items():
+        assert sha(OB.pack_rows(taps[k].numpy().astype(np.uint8))) == info["rows_sha256"], k
+    luts = {}
+    for b in spec.block_tts():
+        luts[b.name], near = OB.build_lut(st, b)
+        assert sha(np.packbits(luts[b.name], axis=1, bitorder="little")) == j["luts"][b.name]["f64_sha256"]
+        assert j["luts"][b.name]["ref_differs_from_f64_at"] == []
+    yb, logits = OB.valexnet_from_stem_bits(taps["features.4"].numpy().astype(np.uint8), st, spec, luts)
+    assert sha(OB.pack_rows(yb)) == j["stages"]["features.5"]["rows_sha256"]
+    assert np.abs(logits - g["logits"]).max() < 2e-5
