@@ -133,7 +133,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=256, help="images per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--variant", default="small", choices=["small", "xsmall", "full"],
+    ap.add_argument("--variant", default="small", choices=["small", "xsmall", "full", "valexnet"],
                     help="small = BASELINE.json configs[1] (the headline); the others are parity-test configs")
     args = ap.parse_args()
 
@@ -145,17 +145,21 @@ def main():
     torch.cuda.set_device(dev)
 
     vargs = dict(nfilter=6, tfilter=10) if args.variant == "full" else dict(nfilter=8, tfilter=8)
-    spec = make_spec(args.variant, **vargs)
+    if args.variant == "valexnet":
+        from scale_imagenet_amd.spec import VAlexSpec
+        spec = VAlexSpec()
+    else:
+        spec = make_spec(args.variant, **vargs)
     st = synth.synth_state_dict(spec)
     cls = {"small": ttnet.TT_vf_19lv3_imgnet_small, "xsmall": ttnet.TT_vf_19lv3_imgnet_xsmall,
-           "full": ttnet.TT_vf_19lv3_imgnet}[args.variant]
+           "full": ttnet.TT_vf_19lv3_imgnet, "valexnet": ttnet.TT_FHE_XSMALL_vAlexnet}[args.variant]
     model = cls(Namespace(layers=1, groups=[1, None, 4, None], **vargs))
     model.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in st.items()}, strict=True)
     model = model.to(dev).eval().reserve(args.batch)
 
     B = args.batch
     n_total = B * world
-    x = torch.from_numpy(synth.synth_images(B, first=rank * B)).to(dev)      # resident in HBM
+    x = torch.from_numpy(synth.synth_images(B, first=rank * B, hw=spec.image_hw)).to(dev)      # resident in HBM
 
     def step():
         with torch.no_grad():
@@ -219,7 +223,8 @@ def main():
         roofline["kernel"] = dom["kernel"]
         roofline["ms"] = dom["ms"]
         out = {
-            "metric": f"images/sec ImageNet 224x224, TT-{args.variant}, MI355X; top-1 exact-match",
+            "metric": (f"images/sec ImageNet 224x224, TT-{args.variant}, MI355X; top-1 exact-match"
+                       if args.variant != "valexnet" else "images/sec CIFAR 32x32, TT vAlexnet variant, MI355X"),
             "value": round(n_total * args.steps / elapsed, 2),
             "unit": "images/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -238,8 +243,9 @@ def main():
             "kernel_ms_sum": round(sum(avg_ms.values()), 5),
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(spec, st)
-            out["gpu_over_cpu"] = round(out["value"] / out["cpu_baseline"]["value"], 1)
+            out["cpu_baseline"] = cpu_baseline(spec, st) if args.variant != "valexnet" else None
+            if out["cpu_baseline"]:
+                out["gpu_over_cpu"] = round(out["value"] / out["cpu_baseline"]["value"], 1)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
