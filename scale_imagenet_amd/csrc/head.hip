@@ -41,20 +41,32 @@ __global__ __launch_bounds__(256) void gemm_nt_splitk_kernel(const float *__rest
 #pragma unroll
   for (int i = 0; i < 16; ++i) acc[i] = 0.f;
 
+  // register double buffering: the global loads of tile t+1 are in flight while tile t is
+  // multiplied (a tile's MFMAs are shorter than a global-load round trip)
+  float4 va[2], vb[2];
+  auto fetch = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int row = lrow + 32 * i;
+      va[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      vb[i] = va[i];
+      const int k = k0 + lk;
+      if (k < kend) {   // K and kper are multiples of 4
+        if (m0 + row < M) va[i] = *(const float4 *)(A + (size_t)(m0 + row) * K + k);
+        if (n0 + row < N) vb[i] = *(const float4 *)(B + (size_t)(n0 + row) * K + k);
+      }
+    }
+  };
+  fetch(kbeg);
   for (int k0 = kbeg; k0 < kend; k0 += BK) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int row = lrow + 32 * i;
-      float4 va = make_float4(0.f, 0.f, 0.f, 0.f), vb = va;
-      const int k = k0 + lk;
-      if (k < kend) {   // K and kper are multiples of 4
-        if (m0 + row < M) va = *(const float4 *)(A + (size_t)(m0 + row) * K + k);
-        if (n0 + row < N) vb = *(const float4 *)(B + (size_t)(n0 + row) * K + k);
-      }
-      As[lk + 0][row] = va.x; As[lk + 1][row] = va.y; As[lk + 2][row] = va.z; As[lk + 3][row] = va.w;
-      Bs[lk + 0][row] = vb.x; Bs[lk + 1][row] = vb.y; Bs[lk + 2][row] = vb.z; Bs[lk + 3][row] = vb.w;
+      As[lk + 0][row] = va[i].x; As[lk + 1][row] = va[i].y; As[lk + 2][row] = va[i].z; As[lk + 3][row] = va[i].w;
+      Bs[lk + 0][row] = vb[i].x; Bs[lk + 1][row] = vb[i].y; Bs[lk + 2][row] = vb[i].z; Bs[lk + 3][row] = vb[i].w;
     }
     __syncthreads();
+    if (k0 + BK < kend) fetch(k0 + BK);
     const int kk0 = lane >> 5, ri = wr * 32 + (lane & 31), ci = wc * 32 + (lane & 31);
 #pragma unroll
     for (int kk = 0; kk < BK; kk += 2) {
