@@ -781,15 +781,16 @@ int ttnet_plan_finalize(ttnet_plan *pl, void *stream) {
     pl->finalized = true;
     return TTNET_OK;
   }
-  // stem: weights split into three bf16 planes in MFMA fragment order; BN folded to fp32 scale/shift
+  // stem: weights split into two prescaled fp16 planes in MFMA fragment order; BN folded to fp32 scale/shift
   {
     std::vector<float> w;
     TT_TRY(fetch(pl->tensors["features.1.weight"], w));
     std::vector<uint16_t> wf(stem_split_weights_elems());
-    stem_split_weights(w.data(), pl->p, wf.data());
+    const double prescale = stem_split_weights(w.data(), pl->p, wf.data());
     TT_HIP(hipMemcpy(pl->stem_wt, wf.data(), wf.size() * 2, hipMemcpyHostToDevice));
     std::vector<double> sc, sh;
     TT_TRY(fold_bn(pl, "features.2", sc, sh));
+    for (double &v : sc) v /= prescale;          // power of two: exact
     TT_TRY(upload_f32(pl->stem_scale, sc));
     TT_TRY(upload_f32(pl->stem_shift, sh));
   }

@@ -94,10 +94,11 @@ struct LutBuildArgs {
 int launch_lut_build(const LutBuildArgs &a, hipStream_t s);
 
 // stem.hip
-// wfrag: the conv weights split into three bf16 planes in MFMA fragment order (stem_split_weights)
+// wfrag: the conv weights split into two fp16 planes in MFMA fragment order (stem_split_weights,
+// which returns the power-of-two operand prescale to divide out of the BN scale)
 int launch_stem(const float *x, const void *wfrag, const float *scale, const float *shift, uint64_t *rp,
                 uint16_t *cp, int n, int p, hipStream_t s);
-void stem_split_weights(const float *w /*[p][3][7][7]*/, int p, uint16_t *out);
+float stem_split_weights(const float *w /*[p][3][7][7]*/, int p, uint16_t *out);
 size_t stem_split_weights_elems();
 
 // gate.hip

@@ -136,6 +136,23 @@ def test_stem_bits(model, variant, dev, oracle_taps):
     assert np.array_equal(rows[:2], g["rows:features.3"]) or len(diff) > 0
 
 
+def test_stem_bits_batch64_vs_float64(small_model, dev):
+    """The fp16 x 2 split stem on 64 images (12.8 M outputs) against the float64 oracle: every
+    bit outside the near-tie band |pre| < 1e-5 equals (pre >= 0)."""
+    n = 64
+    spec, st = spec_and_state("small")
+    xh = synth.synth_images(n)
+    pre = OB.stem_pre64(xh, st)
+    with torch.no_grad():
+        small_model(torch.from_numpy(xh).to(dev))
+    bits = OB.unpack_rows(small_model.read_stage("features.3", n), 56)
+    want = (pre >= 0).astype(np.uint8)
+    bad = np.argwhere(bits != want)
+    worst = max((abs(pre[tuple(d)]) for d in bad), default=0.0)
+    print(f"stem (64 images): {len(bad)} of {bits.size} bits differ from float64, largest |pre| there {worst:.2e}")
+    assert worst < OB.NEAR_TIE
+
+
 def _with_reference_tables(model, variant):
     """Patch the GPU tables with the reference's own near-tie decisions (fixture)."""
     j = golden_json(variant)
