@@ -41,7 +41,7 @@ from scale_imagenet_amd.spec import make_spec
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s achievable)
 F32_PEAK_TFLOPS = 157.3      # fp32 matrix == fp32 vector peak; exact-f32 MFMA
-BF16_PEAK_TFLOPS = 2500.0    # dense bf16 MFMA; the stem issues 6 bf16 products per f32 product (x7/6 kw padding)
+F16_PEAK_TFLOPS = 2500.0     # dense fp16/bf16 MFMA; stem and lin1 issue 3 fp16 products per f32 product (fp16 x 2 split)
 
 # algorithmic work per image; MACs -> 2 flops
 STEM_MAC, LIN1_MAC, LIN2_MAC = 29_503_488, 16_384_000, 1_000_000
@@ -52,8 +52,8 @@ def kernel_models(batch: int):
     """name -> (bound, algorithmic units per launch).  Gate kernels: packed input + output
     bytes of that launch + its tables once (the unfused per-layer accounting of SURVEY 8(d))."""
     m = {
-        "stem": ("mfma_bf16x3", 2.0 * STEM_MAC * batch),
-        "head.lin1": ("mfma_bf16x3", 2.0 * LIN1_MAC * batch),
+        "stem": ("mfma_f16x2", 2.0 * STEM_MAC * batch),
+        "head.lin1": ("mfma_f16x2", 2.0 * LIN1_MAC * batch),
         "head.lin2": ("mfma", 2.0 * LIN2_MAC * batch),
         "head.bn_poly": ("hbm", 8.0 * 1000 * batch),
         "head.bias": ("hbm", 8.0 * 1000 * batch),
@@ -201,20 +201,20 @@ def main():
         kernels = []
         for k, ms in avg_ms.items():
             bound, units = models.get(k, ("hbm", 0.0))
-            if bound == "mfma_bf16x3":
-                # algorithmic f32 flops against the bf16 dense peak; the kernel issues 6 bf16 MFMA
-                # flops per algorithmic flop (operands split 3 x bf16), so frac <= 1/6
-                bound, ach, peak, unit = "mfma", units / (ms * 1e-3) / 1e12, BF16_PEAK_TFLOPS, "TFLOP/s"
+            if bound == "mfma_f16x2":
+                # algorithmic f32 flops against the 16-bit dense peak; the kernel issues 3 fp16 MFMA
+                # flops per algorithmic flop (operands split 2 x fp16), so frac <= 1/3
+                bound, ach, peak, unit = "mfma", units / (ms * 1e-3) / 1e12, F16_PEAK_TFLOPS, "TFLOP/s"
             elif bound == "mfma":
                 ach, peak, unit = units / (ms * 1e-3) / 1e12, F32_PEAK_TFLOPS, "TFLOP/s"
             else:
                 ach, peak, unit = units / (ms * 1e-3) / 1e9, HBM_PEAK_GBS, "GB/s"
             rec = {"kernel": k, "ms": round(ms, 5), "bound": bound, "achieved": round(ach, 3),
                    "peak": peak, "unit": unit, "frac": round(ach / peak, 5), "traffic": traffic.get(k)}
-            if peak == BF16_PEAK_TFLOPS:
-                # MFMA flops the kernel really issues per algorithmic flop: 6 products of the 3-way
-                # bf16 split (stem: x 8/7 for the kw 7 -> 8 padding, x 22/21 for the k-row padding)
-                issued = 6.0 * (8.0 / 7.0) * (22.0 / 21.0) if k == "stem" else 6.0
+            if peak == F16_PEAK_TFLOPS:
+                # MFMA flops the kernel really issues per algorithmic flop: 3 products of the 2-way
+                # fp16 split (stem: x 8/7 for the kw 7 -> 8 padding, x 22/21 for the k-row padding)
+                issued = 3.0 * (8.0 / 7.0) * (22.0 / 21.0) if k == "stem" else 3.0
                 rec["mfma_flops_issued_per_flop"] = round(issued, 3)
                 rec["frac_issued"] = round(ach * issued / peak, 5)
             kernels.append(rec)

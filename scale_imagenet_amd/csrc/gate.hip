@@ -385,24 +385,8 @@ __global__ __launch_bounds__(256) void gate_last_kernel(GateBlockArgs a, const f
     v[d] = tab[(size_t)idx * 16 + k];
   }
   const float f = (((v[0] + v[1]) + v[2]) + v[3]) * 0.25f;
-  // exact 3-way bf16 split, stored where lin1's MFMA fragments expect it:
-  // row = image, k-step = g*PP + pp, lane = (n&31) + 32*(k>>3), element k&7
-  uint32_t u = __float_as_uint(f);
-  u += 0x7FFFu + ((u >> 16) & 1u);
-  const uint32_t b1 = u >> 16;
-  const float r1 = f - __uint_as_float(b1 << 16);
-  u = __float_as_uint(r1);
-  u += 0x7FFFu + ((u >> 16) & 1u);
-  const uint32_t b2 = u >> 16;
-  const float r2 = r1 - __uint_as_float(b2 << 16);
-  u = __float_as_uint(r2);
-  u += 0x7FFFu + ((u >> 16) & 1u);
-  const uint32_t b3 = u >> 16;
-  const int KS = G * PP, ks = g * PP + pp, ln = (n & 31) + 32 * (k >> 3), j = k & 7;
-  const size_t base = ((size_t)(n >> 5) * KS + ks) * 3;
-  feat_frag[((base + 0) * 64 + ln) * 8 + j] = (uint16_t)b1;
-  feat_frag[((base + 1) * 64 + ln) * 8 + j] = (uint16_t)b2;
-  feat_frag[((base + 2) * 64 + ln) * 8 + j] = (uint16_t)b3;
+  // fp16 x 2 split, stored where lin1's MFMA fragments expect it: row = image, k-step = g*PP + pp, k
+  store_feature(feat_frag, n, G * PP, g * PP + pp, k, f);
 }
 
 // ---- layout conversions (parity taps and ttnet_forward_from_stem_bits only) -----------------

@@ -139,7 +139,7 @@ __global__ void rp_majority_kernel(const uint64_t *x, uint64_t *out, int n, int 
   out[nc * Ho + py + pad_t] = r;
 }
 
-// AvgPool2d(2) (floor) of the last block's float output + exact 3-way bf16 split into lin1's
+// AvgPool2d(2) (floor) of the last block's float output + fp16 x 2 split into lin1's
 // fragment order (feature channel ch, pooled pixel pp: k-step (ch/16)*PP + pp, k = ch%16)
 __global__ void full_pool_split_kernel(const float *x, uint16_t *feat_frag, int n, int C, int H, int W) {
   const int Hp = H / 2, Wp = W / 2, PP = Hp * Wp, KS = (C / 16) * PP;
@@ -149,22 +149,7 @@ __global__ void full_pool_split_kernel(const float *x, uint16_t *feat_frag, int 
   const int py = pp / Wp, px = pp % Wp;
   const float *p = x + (((size_t)img * C + ch) * H + 2 * py) * W + 2 * px;
   const float f = (((p[0] + p[1]) + p[W]) + p[W + 1]) * 0.25f;
-  uint32_t u = __float_as_uint(f);
-  u += 0x7FFFu + ((u >> 16) & 1u);
-  const uint32_t b1 = u >> 16;
-  const float r1 = f - __uint_as_float(b1 << 16);
-  u = __float_as_uint(r1);
-  u += 0x7FFFu + ((u >> 16) & 1u);
-  const uint32_t b2 = u >> 16;
-  const float r2 = r1 - __uint_as_float(b2 << 16);
-  u = __float_as_uint(r2);
-  u += 0x7FFFu + ((u >> 16) & 1u);
-  const uint32_t b3 = u >> 16;
-  const int ks = (ch / 16) * PP + pp, kk = ch % 16, ln = (img & 31) + 32 * (kk >> 3), j = kk & 7;
-  const size_t base = ((size_t)(img >> 5) * KS + ks) * 3;
-  feat_frag[((base + 0) * 64 + ln) * 8 + j] = (uint16_t)b1;
-  feat_frag[((base + 1) * 64 + ln) * 8 + j] = (uint16_t)b2;
-  feat_frag[((base + 2) * 64 + ln) * 8 + j] = (uint16_t)b3;
+  store_feature(feat_frag, img, KS, (ch / 16) * PP + pp, ch % 16, f);
 }
 
 }  // namespace

@@ -8,7 +8,7 @@
 //
 // 32x32 inputs and 64- / 256-entry truth tables: a small network; the kernels keep every
 // activation on row-packed planes and favour clarity.  The head reuses head.hip (the 0/1
-// features are exact in bf16, so only the first of the three operand planes is non-zero).
+// features are exact in the split-operand format).
 
 #include "ttnet_common.h"
 
@@ -109,8 +109,8 @@ __global__ void va_c3_kernel(const uint64_t *__restrict__ x_rp, const uint8_t *_
   for (int k = 0; k < 8; ++k) y[((size_t)img * 256 + 128 + 8 * g + k) * 11 + oy] = out[k];
 }
 
-// Flatten (C-major over [256][11][11]) into lin1's fragment-ordered operand: plane 0 = the bit
-// as bf16 1.0 / 0.0; planes 1 and 2 stay zero (allocated zeroed, never written).
+// Flatten (C-major over [256][11][11]) into lin1's fragment-ordered operand (the bit as 0.0 / 1.0:
+// exact in the split format, low term zero).
 __global__ void va_feat_kernel(const uint64_t *__restrict__ y, uint16_t *__restrict__ feat_frag, int n) {
   const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= (size_t)n * 256 * 11) return;
@@ -118,9 +118,8 @@ __global__ void va_feat_kernel(const uint64_t *__restrict__ y, uint16_t *__restr
   const uint64_t r = y[t];
   constexpr int KS = 256 * 121 / 16;
   for (int ox = 0; ox < 11; ++ox) {
-    const int f = ch * 121 + oy * 11 + ox, ks = f >> 4, kk = f & 15;
-    const int ln = (img & 31) + 32 * (kk >> 3), j = kk & 7;
-    feat_frag[((((size_t)(img >> 5) * KS + ks) * 3 + 0) * 64 + ln) * 8 + j] = ((r >> ox) & 1ull) ? 0x3F80 : 0;
+    const int f = ch * 121 + oy * 11 + ox;
+    store_feature(feat_frag, img, KS, f >> 4, f & 15, ((r >> ox) & 1ull) ? 1.0f : 0.0f);
   }
 }
 
@@ -128,8 +127,8 @@ __global__ void va_frag_to_flat_kernel(const uint16_t *__restrict__ af, float *_
   const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   constexpr int K = 256 * 121, KS = K / 16;
   if (t >= (size_t)n * K) return;
-  const int f = t % K, img = t / K, ks = f >> 4, kk = f & 15, ln = (img & 31) + 32 * (kk >> 3), j = kk & 7;
-  out[t] = __uint_as_float((uint32_t)af[((((size_t)(img >> 5) * KS + ks) * 3 + 0) * 64 + ln) * 8 + j] << 16);
+  const int f = t % K, img = t / K;
+  out[t] = load_feature(af, img, KS, f >> 4, f & 15);
 }
 
 }  // namespace

@@ -102,7 +102,7 @@ __global__ void xs_pf_kernel(int n, int C, int Ho, int Wo, int cout_g, const uin
 }
 
 // convf of the last block (float table [C][16][cout_g]) + AvgPool2d(2), features written as
-// three bf16 planes in lin1's fragment order (feature channel ch, pooled pixel pp:
+// two fp16 planes in lin1's fragment order (feature channel ch, pooled pixel pp:
 // k-step = (ch/16)*PP + pp, k = ch%16) -- the same convention as gate_last_kernel.
 __global__ void xs_last_kernel(int n, int C, int Ho, int Wo, int cout_g, const uint64_t *o1, const uint64_t *o2,
                                const uint64_t *o3, const uint64_t *o4, const float *t_last, uint16_t *feat_frag) {
@@ -126,22 +126,7 @@ __global__ void xs_last_kernel(int n, int C, int Ho, int Wo, int cout_g, const u
   for (int k = 0; k < cout_g; ++k) {
     const int ch = c * cout_g + k;
     const float f = acc[k];
-    uint32_t u = __float_as_uint(f);
-    u += 0x7FFFu + ((u >> 16) & 1u);
-    const uint32_t b1 = u >> 16;
-    const float r1 = f - __uint_as_float(b1 << 16);
-    u = __float_as_uint(r1);
-    u += 0x7FFFu + ((u >> 16) & 1u);
-    const uint32_t b2 = u >> 16;
-    const float r2 = r1 - __uint_as_float(b2 << 16);
-    u = __float_as_uint(r2);
-    u += 0x7FFFu + ((u >> 16) & 1u);
-    const uint32_t b3 = u >> 16;
-    const int ks = (ch / 16) * PP + pp, kk = ch % 16, ln = (img & 31) + 32 * (kk >> 3), j = kk & 7;
-    const size_t base = ((size_t)(img >> 5) * KS + ks) * 3;
-    feat_frag[((base + 0) * 64 + ln) * 8 + j] = (uint16_t)b1;
-    feat_frag[((base + 1) * 64 + ln) * 8 + j] = (uint16_t)b2;
-    feat_frag[((base + 2) * 64 + ln) * 8 + j] = (uint16_t)b3;
+    store_feature(feat_frag, img, KS, (ch / 16) * PP + pp, ch % 16, f);
   }
 }
 

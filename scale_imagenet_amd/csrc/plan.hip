@@ -103,15 +103,15 @@ struct ttnet_plan {
   float *last_float = nullptr;      // full variant: relu'd output of the last block before AvgPool2d
 
   // stem
-  uint16_t *stem_wt = nullptr;      // bf16 x 3 split weights, fragment order
+  uint16_t *stem_wt = nullptr;      // fp16 x 2 split weights, fragment order
   float *stem_scale = nullptr, *stem_shift = nullptr;
   // activations: x_rp[i] / x_cp[i] = input of block i
   std::vector<uint64_t *> x_rp;
   std::vector<uint16_t *> x_cp;
-  uint16_t *feat = nullptr;         // features as 3 bf16 planes in lin1 fragment order
+  uint16_t *feat = nullptr;         // features as two fp16 planes in lin1 fragment order
   // head
   float *w1p = nullptr;             // scratch for the permuted lin1 weights (finalize only)
-  uint16_t *w1f = nullptr;          // lin1 weights, 3 bf16 planes in fragment order
+  uint16_t *w1f = nullptr;          // lin1 weights, two fp16 planes in fragment order
   float *bn_scale = nullptr, *bn_shift = nullptr, *part = nullptr, *mid = nullptr;
   size_t part_elems = 0;
   size_t table_bytes = 0, workspace_bytes = 0;
@@ -389,7 +389,7 @@ int allocate(ttnet_plan *pl) {
     TT_TRY(dev_alloc(pl, &pl->mid, (size_t)nb * pl->inter, true, ws));
     size_t pe_va = 0;
     for (int n = 1; n <= nb; ++n)
-      pe_va = std::max(pe_va, (size_t)std::max(gemm_bf16x3_splits(n, pl->inter, pl->fcsize / 16),
+      pe_va = std::max(pe_va, (size_t)std::max(gemm_f16x2_splits(n, pl->inter, pl->fcsize / 16),
                                                gemm_splits(n, pl->n_classes, pl->inter)) * n * pl->inter);
     pl->part_elems = pe_va;
     TT_TRY(dev_alloc(pl, &pl->part, pe_va, false, ws));
@@ -436,7 +436,7 @@ int allocate(ttnet_plan *pl) {
   TT_TRY(dev_alloc(pl, &pl->mid, (size_t)nb * pl->inter, true, ws));
   size_t pe = 0;
   for (int n = 1; n <= nb; ++n) {
-    pe = std::max(pe, (size_t)gemm_bf16x3_splits(n, pl->inter, pl->fcsize / 16) * n * pl->inter);
+    pe = std::max(pe, (size_t)gemm_f16x2_splits(n, pl->inter, pl->fcsize / 16) * n * pl->inter);
     pe = std::max(pe, (size_t)gemm_splits(n, pl->n_classes, pl->inter) * n * pl->n_classes);
   }
   pl->part_elems = pe;
@@ -594,8 +594,8 @@ int run_va_tail(ttnet_plan *pl, int n, float *logits, hipStream_t s) {
   MultiHead &mh = pl->blocks[0];
   TT_TIMED(pl, "va.block", s, launch_va_block(pl->x_rp[0], mh.c1.table, mh.c2.table, mh.c3.table, pl->va_y, n, s));
   TT_TIMED(pl, "va.flatten", s, launch_va_feat(pl->va_y, pl->feat, n, s));
-  const int s1 = gemm_bf16x3_splits(n, pl->inter, pl->fcsize / 16);
-  TT_TIMED(pl, "head.lin1", s, launch_gemm_bf16x3(pl->feat, pl->w1f, pl->part, n, pl->inter, pl->fcsize, s1, s));
+  const int s1 = gemm_f16x2_splits(n, pl->inter, pl->fcsize / 16);
+  TT_TIMED(pl, "head.lin1", s, launch_gemm_f16x2(pl->feat, pl->w1f, pl->part, n, pl->inter, pl->fcsize, s1, s));
   TT_TIMED(pl, "head.bn", s, launch_head_mid(pl->part, s1, pl->bn_scale, pl->bn_shift, pl->mid, n, pl->inter, 0, s));
   const int s2 = gemm_splits(n, pl->n_classes, pl->inter);
   TT_TIMED(pl, "head.lin2", s,
@@ -635,8 +635,8 @@ int run_from_blocks(ttnet_plan *pl, int n, float *logits, hipStream_t s) {
       TT_TIMED(pl, "gate_last", s, launch_gate_last(a, (const float *)mh.cf.table, pl->feat, s));
     }
   }
-  const int s1 = gemm_bf16x3_splits(n, pl->inter, pl->fcsize / 16);
-  TT_TIMED(pl, "head.lin1", s, launch_gemm_bf16x3(pl->feat, pl->w1f, pl->part, n, pl->inter, pl->fcsize, s1, s));
+  const int s1 = gemm_f16x2_splits(n, pl->inter, pl->fcsize / 16);
+  TT_TIMED(pl, "head.lin1", s, launch_gemm_f16x2(pl->feat, pl->w1f, pl->part, n, pl->inter, pl->fcsize, s1, s));
   TT_TIMED(pl, "head.bn_poly", s, launch_head_mid(pl->part, s1, pl->bn_scale, pl->bn_shift, pl->mid, n, pl->inter, 1, s));
   const int s2 = gemm_splits(n, pl->n_classes, pl->inter);
   TT_TIMED(pl, "head.lin2", s,
@@ -768,9 +768,17 @@ int ttnet_plan_finalize(ttnet_plan *pl, void *stream) {
     TT_TRY(upload_f32(pl->va_shift, sh));
     for (BlockTT *b : all_block_tts(pl)) TT_TRY(build_table(pl, *b, s));
     TT_TRY(fold_bn(pl, "features.7.BN2", sc, sh));
+    float ws1 = 1.f;
+    {
+      std::vector<float> w1;
+      TT_TRY(fetch(pl->tensors["features.7.lin1.weight"], w1));
+      ws1 = weight_prescale(w1.data(), w1.size());
+    }
+    for (double &v : sc) v /= (double)ws1 * ACT_PRESCALE;      // operand prescales (powers of two) out of lin1's result
     TT_TRY(upload_f32(pl->bn_scale, sc));
     TT_TRY(upload_f32(pl->bn_shift, sh));
-    TT_TRY(launch_split_to_frag((const float *)pl->tensors["features.7.lin1.weight"].dev, pl->w1f, pl->inter, pl->fcsize, 128, s));
+    TT_TRY(launch_split_to_frag((const float *)pl->tensors["features.7.lin1.weight"].dev, pl->w1f, pl->inter, pl->fcsize, 128, ws1,
+                                s));
     TT_HIP(hipStreamSynchronize(s));
     for (BlockTT *b : all_block_tts(pl)) {
       if (b->user_table) continue;
@@ -799,11 +807,18 @@ int ttnet_plan_finalize(ttnet_plan *pl, void *stream) {
   {
     std::vector<double> sc, sh;
     TT_TRY(fold_bn(pl, pl->head + ".BN2", sc, sh));
+    float ws1 = 1.f;
+    {
+      std::vector<float> w1;
+      TT_TRY(fetch(pl->tensors[pl->head + ".lin1.weight"], w1));
+      ws1 = weight_prescale(w1.data(), w1.size());
+    }
+    for (double &v : sc) v /= (double)ws1 * ACT_PRESCALE;      // operand prescales (powers of two) out of lin1's result
     TT_TRY(upload_f32(pl->bn_scale, sc));
     TT_TRY(upload_f32(pl->bn_shift, sh));
     TT_TRY(launch_permute_lin1((const float *)pl->tensors[pl->head + ".lin1.weight"].dev, pl->w1p, pl->inter,
                                pl->featC / 16, pl->featPP, s));
-    TT_TRY(launch_split_to_frag(pl->w1p, pl->w1f, pl->inter, pl->fcsize, (pl->inter + 127) / 128 * 128, s));
+    TT_TRY(launch_split_to_frag(pl->w1p, pl->w1f, pl->inter, pl->fcsize, (pl->inter + 127) / 128 * 128, ws1, s));
   }
   TT_HIP(hipStreamSynchronize(s));
   for (auto &mh : pl->blocks)

@@ -50,8 +50,8 @@ constexpr int KSTEPS = 11;             // 22 (c,kh) rows (21 + one zero row), tw
 constexpr int NT = SR * 56 / 32;       // 14 N-tiles of 32 pixels
 constexpr int PLANE = 3 * TR * TW;     // elements per fp16 plane
 
-constexpr int NPL = 2;                 // fp16 planes per operand
-constexpr float X_PRESCALE = 16.0f;
+constexpr int NPL = SPLIT_PLANES;      // fp16 planes per operand
+constexpr float X_PRESCALE = ACT_PRESCALE;
 
 constexpr int CONS_WAVES = 8, PROD_WAVES = 4, STEM_THREADS = 64 * (CONS_WAVES + PROD_WAVES);
 constexpr int UNITS = NT * 2;          // (N-tile, M-tile) pairs of one item: 28
@@ -59,7 +59,7 @@ constexpr int UPW = (UNITS + CONS_WAVES - 1) / CONS_WAVES;   // units per consum
 
 // Persistent producer / consumer kernel.  One workgroup per CU walks items (image, block of SR
 // output rows).  Producer waves stream the raw float32 rows from HBM, pool them and write the
-// three bf16 planes of the NEXT item's tile into the other half of an LDS double buffer;
+// two fp16 planes of the NEXT item's tile into the other half of an LDS double buffer;
 // consumer waves run the MFMAs and the BN/sign/pack epilogue of the CURRENT item.  One
 // workgroup barrier per item.  (With build -> MFMA -> epilogue serial inside a workgroup the
 // kernel idled the matrix pipe and HBM alternately: 116 us at B = 256 against a 43 us MFMA
@@ -283,17 +283,7 @@ static float f16_to_f32(uint16_t h) {
 }
 
 float stem_split_weights(const float *w, int p, uint16_t *out) {
-  float amax = 0.f;
-  for (int i = 0; i < p * 147; ++i) amax = fmaxf(amax, fabsf(w[i]));
-  int k = 0;
-  if (amax > 0.f && std::isfinite(amax)) {
-    int e;
-    frexpf(amax, &e);            // amax = f * 2^e, f in [0.5, 1)
-    k = 14 - e;                  // amax * 2^k in [8192, 16384)
-  }
-  if (k > 40) k = 40;
-  if (k < -100) k = -100;
-  const float ws = ldexpf(1.0f, k);
+  const float ws = weight_prescale(w, (size_t)p * 147);
   for (int ks = 0; ks < KSTEPS; ++ks)
     for (int m = 0; m < 2; ++m)
       for (int l = 0; l < 64; ++l)

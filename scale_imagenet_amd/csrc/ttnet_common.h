@@ -93,6 +93,41 @@ struct LutBuildArgs {
 };
 int launch_lut_build(const LutBuildArgs &a, hipStream_t s);
 
+// ---- split-operand format shared by the stem and lin1 (arithmetic: see stem.hip) -----------
+// A float32 value, prescaled by a power of two, is carried as two fp16 terms h1 + h2
+// (22 significant bits).  Activations use the fixed prescale ACT_PRESCALE; each weight tensor
+// uses its own (weight_prescale); the product of the two is divided out of the BatchNorm scale
+// that follows.  Fragment order of an operand: [tile32][kstep16][plane][lane][8 fp16], lane l
+// holding row 32*tile + (l & 31), k = 16*kstep + 8*(l >> 5) + j.
+constexpr int SPLIT_PLANES = 2;
+constexpr float ACT_PRESCALE = 16.0f;      // |activation| < 4094
+
+__device__ inline void split_f16x2(float v, uint16_t &h1, uint16_t &h2) {
+  const _Float16 a = (_Float16)v;
+  const _Float16 b = (_Float16)(v - (float)a);
+  h1 = __builtin_bit_cast(uint16_t, a);
+  h2 = __builtin_bit_cast(uint16_t, b);
+}
+__device__ inline float f16_bits_to_float(uint16_t h) { return (float)__builtin_bit_cast(_Float16, h); }
+
+// feature (image img, k-step ks of KS, element kk of 16) into lin1's A operand
+__device__ inline void store_feature(uint16_t *feat_frag, int img, int KS, int ks, int kk, float f) {
+  uint16_t h1, h2;
+  split_f16x2(f * ACT_PRESCALE, h1, h2);
+  const int ln = (img & 31) + 32 * (kk >> 3), j = kk & 7;
+  const size_t base = ((size_t)(img >> 5) * KS + ks) * SPLIT_PLANES;
+  feat_frag[((base + 0) * 64 + ln) * 8 + j] = h1;
+  feat_frag[((base + 1) * 64 + ln) * 8 + j] = h2;
+}
+__device__ inline float load_feature(const uint16_t *feat_frag, int img, int KS, int ks, int kk) {
+  const int ln = (img & 31) + 32 * (kk >> 3), j = kk & 7;
+  const size_t base = ((size_t)(img >> 5) * KS + ks) * SPLIT_PLANES;
+  return (f16_bits_to_float(feat_frag[((base + 1) * 64 + ln) * 8 + j]) + f16_bits_to_float(feat_frag[((base + 0) * 64 + ln) * 8 + j])) *
+         (1.0f / ACT_PRESCALE);
+}
+// host: the power of two that brings max|w| into [8192, 16384) (1 for an all-zero / non-finite tensor)
+float weight_prescale(const float *w, size_t n);
+
 // stem.hip
 // wfrag: the conv weights split into two fp16 planes in MFMA fragment order (stem_split_weights,
 // which returns the power-of-two operand prescale to divide out of the BN scale)
@@ -120,7 +155,7 @@ int launch_gate_stage1(const GateBlockArgs &a, hipStream_t s);
 // [n][Cout][Ho], Cout = 8 * (4C/16)
 int launch_gate_pf(const GateBlockArgs &a, const uint8_t *t_cf, uint16_t *out_cp, uint64_t *out_rp, hipStream_t s);
 // convf of the last block through the float table, AvgPool2d(2) fused; the features are
-// written pre-split for lin1: fragment-ordered bf16 planes [n/32][(g*PP+pp)][3][64][8]
+// written pre-split for lin1: fragment-ordered fp16 planes [n/32][(g*PP+pp)][2][64][8]
 int launch_gate_last(const GateBlockArgs &a, const float *t_last, void *feat_frag, hipStream_t s);
 // x-small variant (fan-in 4, gate_xs.hip): everything on row-packed planes
 int launch_xs_branches(const GateBlockArgs &a, const void *t_c3, uint64_t *const o[4], hipStream_t s);
@@ -166,11 +201,11 @@ int launch_cp_to_rp(const uint16_t *cp, uint64_t *rp, int n, int C, int H, int W
 int launch_rp_to_cp(const uint64_t *rp, uint16_t *cp, int n, int C, int H, int W, hipStream_t s);
 // feature planes (fragment order) -> float32 [n][(16g+k)*PP + pp] (reference Flatten order)
 int launch_frag_to_reference_order(const void *af, float *out, int n, int G, int PP, hipStream_t s);
-// bf16 x 3 split GEMM on fragment-ordered operands: part[splits][M][N]
-int gemm_bf16x3_splits(int M, int N, int KS);
-int launch_gemm_bf16x3(const void *Af, const void *Bf, float *part, int M, int N, int K, int splits, hipStream_t s);
+// fp16 x 2 split GEMM on fragment-ordered operands: part[splits][M][N]
+int gemm_f16x2_splits(int M, int N, int KS);
+int launch_gemm_f16x2(const void *Af, const void *Bf, float *part, int M, int N, int K, int splits, hipStream_t s);
 size_t frag_elems(int rows, int K);
-int launch_split_to_frag(const float *src, void *dst, int R, int K, int rows_padded, hipStream_t s);
+int launch_split_to_frag(const float *src, void *dst, int R, int K, int rows_padded, float prescale, hipStream_t s);
 
 // head.hip
 // C[M][N] (+)= A[M][K] * B[N][K]^T as split-K slabs: part[S][M][N]

@@ -292,8 +292,9 @@ def test_random_bits_against_bit_oracle(model, variant, dev):
         if stage == spec.blocks[-1].name:                 # float output of the last block: see "flatten"
             continue
         if stage == "flatten":
-            # float32 table entries (float64 values rounded once) averaged in float32
-            assert np.abs(model.read_stage("flatten", 3) - bt[stage]).max() <= 2e-7 * max(1.0, np.abs(bt[stage]).max()) + 1e-6
+            # float32 table entries (float64 values rounded once) averaged in float32, read back
+            # from lin1's fp16 x 2 operand format (22 significant bits)
+            assert np.abs(model.read_stage("flatten", 3) - bt[stage]).max() <= 5e-7 * max(1.0, np.abs(bt[stage]).max()) + 1e-6
         else:
             assert np.array_equal(model.read_stage(stage, 3), OB.pack_rows(bt[stage])), stage
     assert np.abs(y - ref).max() <= 2e-5
