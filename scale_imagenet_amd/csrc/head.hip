@@ -11,13 +11,15 @@
 //        gemm_f16x2_kernel.  Operands are stored pre-split in MFMA fragment order
 //        ([tile32][kstep16][plane][lane][8 fp16]) so that every global->LDS transfer and every
 //        LDS fragment read is a linear 1 KiB block.
-//   lin2 (K = 1000) stays on the exact-fp32 instruction v_mfma_f32_32x32x2_f32.
-// M = images is small (256), so K is split across workgroups to fill the 256 CUs; partial
-// slabs are summed by the fused epilogue kernels in a fixed order (bitwise reproducible, no
-// float atomics).
+//   lin2 (K = 1000, padded to 1008) uses the same split operands in one small kernel
+//        (lin2_f16x2_kernel): 64x64 output tile per workgroup, K split over its 8 waves,
+//        partial tiles summed through LDS in wave order, bias fused.
+// M = images is small (256), so lin1's K is split across workgroups to fill the 256 CUs; the
+// partial slabs are summed in a fixed order by head_mid_kernel (bitwise reproducible, no float
+// atomics), which also applies BatchNorm1d + the polynomial and writes lin2's A operand.
 //
 // Bound: lin1 16-bit MFMA (3 MFMA flops per algorithmic flop) / HBM (66 MB of split weights
-// read once per batch); lin2 fp32 MFMA.
+// read once per batch); lin2 latency.
 
 #include <cmath>
 
@@ -28,68 +30,6 @@ namespace ttnet {
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-constexpr int BM = 64, BN = 64, BK = 32, LDT = BM + 1;
-
-__global__ __launch_bounds__(256) void gemm_nt_splitk_kernel(const float *__restrict__ A, const float *__restrict__ B,
-                                                            float *__restrict__ part, int M, int N, int K,
-                                                            int kper) {
-  __shared__ float As[BK][LDT];
-  __shared__ float Bs[BK][LDT];
-  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
-  const int kbeg = blockIdx.z * kper, kend = min(K, kbeg + kper);
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wr = wave >> 1, wc = wave & 1;
-  const int lrow = tid >> 3, lk = (tid & 7) * 4;
-  f32x16 acc;
-#pragma unroll
-  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-
-  // register double buffering: the global loads of tile t+1 are in flight while tile t is
-  // multiplied (a tile's MFMAs are shorter than a global-load round trip)
-  float4 va[2], vb[2];
-  auto fetch = [&](int k0) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int row = lrow + 32 * i;
-      va[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-      vb[i] = va[i];
-      const int k = k0 + lk;
-      if (k < kend) {   // K and kper are multiples of 4
-        if (m0 + row < M) va[i] = *(const float4 *)(A + (size_t)(m0 + row) * K + k);
-        if (n0 + row < N) vb[i] = *(const float4 *)(B + (size_t)(n0 + row) * K + k);
-      }
-    }
-  };
-  fetch(kbeg);
-  for (int k0 = kbeg; k0 < kend; k0 += BK) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int row = lrow + 32 * i;
-      As[lk + 0][row] = va[i].x; As[lk + 1][row] = va[i].y; As[lk + 2][row] = va[i].z; As[lk + 3][row] = va[i].w;
-      Bs[lk + 0][row] = vb[i].x; Bs[lk + 1][row] = vb[i].y; Bs[lk + 2][row] = vb[i].z; Bs[lk + 3][row] = vb[i].w;
-    }
-    __syncthreads();
-    if (k0 + BK < kend) fetch(k0 + BK);
-    const int kk0 = lane >> 5, ri = wr * 32 + (lane & 31), ci = wc * 32 + (lane & 31);
-#pragma unroll
-    for (int kk = 0; kk < BK; kk += 2) {
-      const float a = As[kk + kk0][ri];
-      const float b = Bs[kk + kk0][ci];
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
-    }
-    __syncthreads();
-  }
-  // C/D layout of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
-  float *dst = part + (size_t)blockIdx.z * M * N;
-  const int col = n0 + wc * 32 + (lane & 31);
-#pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int row = m0 + wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-    if (row < M && col < N) dst[(size_t)row * N + col] = acc[r];
-  }
-}
-
 
 // ---- fp16 x 2 split GEMM in fragment order ----------------------------------------------------
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
@@ -223,9 +163,10 @@ __global__ __launch_bounds__(64 * G_WAVES) void gemm_f16x2_kernel(const uint8_t 
     }
 }
 
-// float32 row-major [R][K] x prescale -> fragment-ordered fp16 planes [ceil(R/32)][K/16][NP][64][8] (rows >= R: 0)
+// float32 row-major [R][ld] x prescale -> fragment-ordered fp16 planes [tiles][K/16][NP][64][8]
+// (rows >= R and k >= kvalid: 0; K is the padded multiple of 16)
 __global__ void split_to_frag_kernel(const float *__restrict__ src, uint16_t *__restrict__ dst, int R, int K, int tiles,
-                                     float prescale) {
+                                     float prescale, int ld, int kvalid) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;       // one (tile, kstep, lane, j)
   const int KS = K / 16;
   if (i >= (size_t)tiles * KS * 64 * 8) return;
@@ -233,7 +174,7 @@ __global__ void split_to_frag_kernel(const float *__restrict__ src, uint16_t *__
   const size_t tk = i / 512;
   const int ks = tk % KS, tl = tk / KS;
   const int row = tl * 32 + (ln & 31), k = ks * 16 + 8 * (ln >> 5) + j;
-  const float v = row < R ? src[(size_t)row * K + k] * prescale : 0.f;
+  const float v = row < R && k < kvalid ? src[(size_t)row * ld + k] * prescale : 0.f;
   uint16_t h1, h2;
   split_f16x2(v, h1, h2);
   const size_t base = ((size_t)tl * KS + ks) * NP;
@@ -251,32 +192,94 @@ __global__ void frag_to_ref_kernel(const uint16_t *__restrict__ af, float *__res
   out[(size_t)img * per + ((size_t)(16 * g + kk)) * PP + pp] = load_feature(af, img, G * PP, g * PP + pp, kk);
 }
 
+// sum of lin1's K-slices (fixed order) -> BatchNorm1d -> polynomial -> lin2's A operand
+// (fragment order, KS2 = ceil(N/16) k-steps; the k padding stays zero from allocation)
 __global__ void head_mid_kernel(const float *__restrict__ part, int splits, const float *__restrict__ scale,
-                                const float *__restrict__ shift, float *__restrict__ out, int M, int N, int polynomial) {
+                                const float *__restrict__ shift, uint16_t *__restrict__ mid_frag, int M, int N,
+                                int polynomial) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (size_t)M * N) return;
-  const int nidx = i % N;
+  const int nidx = i % N, row = i / N;
   double s = 0.0;
 #pragma unroll 8
   for (int z = 0; z < splits; ++z) s += (double)part[(size_t)z * M * N + i];      // fixed order: reproducible
-  const float zf = fmaf((float)s, scale[nidx], shift[nidx]);
-  if (!polynomial) {                     // vAlexnet's Classifier_scale has no activation (:671-675)
-    out[i] = zf;
-    return;
+  float y = fmaf((float)s, scale[nidx], shift[nidx]);
+  if (polynomial) {                      // vAlexnet's Classifier_scale has no activation (:671-675)
+    // 0.47 + 0.50 * x + 0.09 * x ** 2, evaluated left to right in fp32 like the reference
+    const float t = __fadd_rn(0.47f, __fmul_rn(0.50f, y));
+    y = __fadd_rn(t, __fmul_rn(0.09f, __fmul_rn(y, y)));
   }
-  // 0.47 + 0.50 * x + 0.09 * x ** 2, evaluated left to right in fp32 like the reference
-  const float t = __fadd_rn(0.47f, __fmul_rn(0.50f, zf));
-  out[i] = __fadd_rn(t, __fmul_rn(0.09f, __fmul_rn(zf, zf)));
+  store_feature(mid_frag, row, (N + 15) / 16, nidx >> 4, nidx & 15, y);
 }
 
-__global__ void head_out_kernel(const float *__restrict__ part, int splits, const float *__restrict__ bias,
-                                float *__restrict__ out, int M, int N) {
-  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= (size_t)M * N) return;
-  double s = 0.0;
-#pragma unroll 8
-  for (int z = 0; z < splits; ++z) s += (double)part[(size_t)z * M * N + i];
-  out[i] = (float)(s + (double)bias[i % N]);
+// ---- lin2: out[M][N] = A[M][K] * B[N][K]^T * inv + bias, split operands in fragment order ----
+// A: [ceil(M/64)*2][KS][NP][64][8], B: [ceil(N/64)*2][KS][NP][64][8] (tile rows padded to 64).
+constexpr int L2_WAVES = 8, L2_STAGES = 4, L2_LDS = L2_WAVES * 4 * 16 * 64 * 4;
+__global__ __launch_bounds__(64 * L2_WAVES) void lin2_f16x2_kernel(const uint4 *__restrict__ A, const uint4 *__restrict__ B,
+                                                                   const float *__restrict__ bias, float inv,
+                                                                   float *__restrict__ out, int M, int N, int KS) {
+  extern __shared__ __align__(16) float red[];          // [wave][tile][reg][lane]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int mt0 = blockIdx.y * 2, nt0 = blockIdx.x * 2;
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  const int nk = wave < KS ? (KS - wave + L2_WAVES - 1) / L2_WAVES : 0;      // this wave's k-steps: wave + 8 i
+  uint4 fa[L2_STAGES][2][NP], fb[L2_STAGES][2][NP];
+  auto load = [&](int i, uint4 (&a)[2][NP], uint4 (&b)[2][NP]) {
+    const int ks = wave + L2_WAVES * i;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int pl = 0; pl < NP; ++pl) {
+        a[t][pl] = A[(((size_t)(mt0 + t) * KS + ks) * NP + pl) * 64 + lane];
+        b[t][pl] = B[(((size_t)(nt0 + t) * KS + ks) * NP + pl) * 64 + lane];
+      }
+  };
+  static_for<0, L2_STAGES>([&](auto ss) {
+    constexpr int sl = decltype(ss)::value;
+    if (sl < nk) load(sl, fa[sl], fb[sl]);
+  });
+  for (int i0 = 0; i0 < nk; i0 += L2_STAGES) {
+    static_for<0, L2_STAGES>([&](auto ss) {
+      constexpr int sl = decltype(ss)::value;
+      if (i0 + sl < nk) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            const f16x8 a0 = __builtin_bit_cast(f16x8, fa[sl][i][0]), a1 = __builtin_bit_cast(f16x8, fa[sl][i][1]);
+            const f16x8 b0 = __builtin_bit_cast(f16x8, fb[sl][j][0]), b1 = __builtin_bit_cast(f16x8, fb[sl][j][1]);
+            f32x16 c = acc[i][j];
+            c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b0, c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b1, c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b0, c, 0, 0, 0);
+            acc[i][j] = c;
+          }
+        if (i0 + sl + L2_STAGES < nk) load(i0 + sl + L2_STAGES, fa[sl], fb[sl]);
+      }
+    });
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) red[((wave * 4 + i * 2 + j) * 16 + r) * 64 + lane] = acc[i][j][r];
+  __syncthreads();
+  for (int e = threadIdx.x; e < 4 * 16 * 64; e += 64 * L2_WAVES) {
+    double sum = 0.0;
+#pragma unroll
+    for (int w = 0; w < L2_WAVES; ++w) sum += (double)red[w * (4 * 16 * 64) + e];      // wave order: reproducible
+    const int ln = e & 63, r = (e >> 6) & 15, t = e >> 10;
+    const int row = (mt0 + (t >> 1)) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (ln >> 5);
+    const int col = (nt0 + (t & 1)) * 32 + (ln & 31);
+    if (row < M && col < N) out[(size_t)row * N + col] = (float)(sum * (double)inv + (double)bias[col]);
+  }
 }
 
 __global__ void permute_lin1_kernel(const float *__restrict__ w1, float *__restrict__ w1p, int O, int G, int PP) {
@@ -289,20 +292,6 @@ __global__ void permute_lin1_kernel(const float *__restrict__ w1, float *__restr
 }
 
 }  // namespace
-
-int launch_gemm_nt_splitk(const float *A, const float *B, float *part, int M, int N, int K, int splits,
-                          hipStream_t s) {
-  if (K % 4) {
-    set_error("gemm: K=%d must be a multiple of 4", K);
-    return TTNET_E_UNSUPPORTED;
-  }
-  int kper = ((K + splits - 1) / splits + BK - 1) / BK * BK;
-  dim3 grid((N + BN - 1) / BN, (M + BM - 1) / BM, splits);
-  hipLaunchKernelGGL(gemm_nt_splitk_kernel, grid, dim3(256), 0, s, A, B, part, M, N, K, kper);
-  TT_HIP(hipGetLastError());
-  return TTNET_OK;
-}
-
 
 int gemm_f16x2_splits(int M, int N, int KS) {
   const int tiles = ((M + G_BM - 1) / G_BM) * ((N + G_BN - 1) / G_BN);
@@ -338,11 +327,16 @@ float weight_prescale(const float *w, size_t n) {
   return ldexpf(1.0f, k);
 }
 
-int launch_split_to_frag(const float *src, void *dst, int R, int K, int rows_padded, float prescale, hipStream_t s) {
+int launch_split_to_frag(const float *src, void *dst, int R, int K, int rows_padded, float prescale, hipStream_t s, int ld,
+                         int kvalid) {
+  if (K % 16) {
+    set_error("split_to_frag: K=%d is not a multiple of 16", K);
+    return TTNET_E_UNSUPPORTED;
+  }
   const int tiles = (rows_padded + 31) / 32;
   const size_t t = (size_t)tiles * (K / 16) * 64 * 8;
   hipLaunchKernelGGL(split_to_frag_kernel, dim3((unsigned)((t + 255) / 256)), dim3(256), 0, s, src, (uint16_t *)dst, R, K, tiles,
-                     prescale);
+                     prescale, ld > 0 ? ld : K, kvalid > 0 ? kvalid : K);
   TT_HIP(hipGetLastError());
   return TTNET_OK;
 }
@@ -354,19 +348,21 @@ int launch_frag_to_reference_order(const void *af, float *out, int n, int G, int
   return TTNET_OK;
 }
 
-int launch_head_mid(const float *part, int splits, const float *scale, const float *shift, float *out, int M,
-                    int N, int polynomial, hipStream_t s) {
+int launch_head_mid(const float *part, int splits, const float *scale, const float *shift, void *mid_frag, int M, int N,
+                    int polynomial, hipStream_t s) {
   const size_t t = (size_t)M * N;
   hipLaunchKernelGGL(head_mid_kernel, dim3((unsigned)((t + 255) / 256)), dim3(256), 0, s, part, splits, scale, shift,
-                     out, M, N, polynomial);
+                     (uint16_t *)mid_frag, M, N, polynomial);
   TT_HIP(hipGetLastError());
   return TTNET_OK;
 }
 
-int launch_head_out(const float *part, int splits, const float *bias, float *out, int M, int N, hipStream_t s) {
-  const size_t t = (size_t)M * N;
-  hipLaunchKernelGGL(head_out_kernel, dim3((unsigned)((t + 255) / 256)), dim3(256), 0, s, part, splits, bias, out, M,
-                     N);
+int launch_lin2_f16x2(const void *mid_frag, const void *w2f, const float *bias, float inv, float *out, int M, int N, int K,
+                      hipStream_t s) {
+  const int KS = (K + 15) / 16;
+  TT_HIP(hipFuncSetAttribute((const void *)lin2_f16x2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, L2_LDS));
+  hipLaunchKernelGGL(lin2_f16x2_kernel, dim3((N + 63) / 64, (M + 63) / 64), dim3(64 * L2_WAVES), L2_LDS, s,
+                     (const uint4 *)mid_frag, (const uint4 *)w2f, bias, inv, out, M, N, KS);
   TT_HIP(hipGetLastError());
   return TTNET_OK;
 }

@@ -112,7 +112,10 @@ struct ttnet_plan {
   // head
   float *w1p = nullptr;             // scratch for the permuted lin1 weights (finalize only)
   uint16_t *w1f = nullptr;          // lin1 weights, two fp16 planes in fragment order
-  float *bn_scale = nullptr, *bn_shift = nullptr, *part = nullptr, *mid = nullptr;
+  float *bn_scale = nullptr, *bn_shift = nullptr, *part = nullptr;
+  uint16_t *mid_frag = nullptr;     // lin2's A operand (head_mid_kernel), rows padded to 64
+  uint16_t *w2f = nullptr;          // lin2 weights, split planes in fragment order, K padded to 16
+  float lin2_inv = 1.f;             // 1 / (weight prescale x activation prescale)
   size_t part_elems = 0;
   size_t table_bytes = 0, workspace_bytes = 0;
   int64_t last_n = 0;
@@ -350,12 +353,13 @@ int build_geometry(ttnet_plan *pl) {
   return TTNET_OK;
 }
 
-int gemm_splits(int m, int n, int k) {
-  const int tiles = ((m + 63) / 64) * ((n + 63) / 64);
-  int s = 1024 / tiles;
-  s = std::max(1, std::min(s, 64));
-  s = std::min(s, std::max(1, k / 128));
-  return s;
+// lin2 operands: A = head_mid's output (rows padded to 64, zeroed once so that the k padding is 0),
+// B = the split weights (rows padded to 64)
+int alloc_lin2(ttnet_plan *pl, int nb, size_t *ws) {
+  const int kpad = (pl->inter + 15) / 16 * 16;
+  TT_TRY(dev_alloc(pl, &pl->mid_frag, frag_elems((nb + 63) / 64 * 64, kpad), true, ws));
+  TT_TRY(dev_alloc(pl, &pl->w2f, frag_elems((pl->n_classes + 63) / 64 * 64, kpad), true));
+  return TTNET_OK;
 }
 
 int allocate(ttnet_plan *pl) {
@@ -386,11 +390,9 @@ int allocate(ttnet_plan *pl) {
     TT_TRY(dev_alloc(pl, &pl->w1f, frag_elems(128, pl->fcsize), false));
     TT_TRY(dev_alloc(pl, &pl->bn_scale, pl->inter, false));
     TT_TRY(dev_alloc(pl, &pl->bn_shift, pl->inter, false));
-    TT_TRY(dev_alloc(pl, &pl->mid, (size_t)nb * pl->inter, true, ws));
+    TT_TRY(alloc_lin2(pl, nb, ws));
     size_t pe_va = 0;
-    for (int n = 1; n <= nb; ++n)
-      pe_va = std::max(pe_va, (size_t)std::max(gemm_f16x2_splits(n, pl->inter, pl->fcsize / 16),
-                                               gemm_splits(n, pl->n_classes, pl->inter)) * n * pl->inter);
+    for (int n = 1; n <= nb; ++n) pe_va = std::max(pe_va, (size_t)gemm_f16x2_splits(n, pl->inter, pl->fcsize / 16) * n * pl->inter);
     pl->part_elems = pe_va;
     TT_TRY(dev_alloc(pl, &pl->part, pe_va, false, ws));
     return TTNET_OK;
@@ -433,12 +435,9 @@ int allocate(ttnet_plan *pl) {
   TT_TRY(dev_alloc(pl, &pl->w1f, frag_elems((pl->inter + 127) / 128 * 128, pl->fcsize), false));
   TT_TRY(dev_alloc(pl, &pl->bn_scale, pl->inter, false));
   TT_TRY(dev_alloc(pl, &pl->bn_shift, pl->inter, false));
-  TT_TRY(dev_alloc(pl, &pl->mid, (size_t)nb * pl->inter, true, ws));
+  TT_TRY(alloc_lin2(pl, nb, ws));
   size_t pe = 0;
-  for (int n = 1; n <= nb; ++n) {
-    pe = std::max(pe, (size_t)gemm_f16x2_splits(n, pl->inter, pl->fcsize / 16) * n * pl->inter);
-    pe = std::max(pe, (size_t)gemm_splits(n, pl->n_classes, pl->inter) * n * pl->n_classes);
-  }
+  for (int n = 1; n <= nb; ++n) pe = std::max(pe, (size_t)gemm_f16x2_splits(n, pl->inter, pl->fcsize / 16) * n * pl->inter);
   pl->part_elems = pe;
   TT_TRY(dev_alloc(pl, &pl->part, pe, false, ws));
   return TTNET_OK;
@@ -589,21 +588,35 @@ int run_full_block(ttnet_plan *pl, size_t i, int n, hipStream_t s) {
   return TTNET_OK;
 }
 
+// split lin2.weight into w2f (finalize)
+int prepare_lin2(ttnet_plan *pl, const std::string &key, hipStream_t s) {
+  std::vector<float> w2;
+  TT_TRY(fetch(pl->tensors[key], w2));
+  const float ws2 = weight_prescale(w2.data(), w2.size());
+  pl->lin2_inv = 1.0f / (ws2 * ACT_PRESCALE);
+  const int kpad = (pl->inter + 15) / 16 * 16;
+  return launch_split_to_frag((const float *)pl->tensors[key].dev, pl->w2f, pl->n_classes, kpad, (pl->n_classes + 63) / 64 * 64, ws2, s,
+                              pl->inter, pl->inter);
+}
+
+// Classifier_scale from the features in pl->feat
+int run_head(ttnet_plan *pl, int n, float *logits, int polynomial, const std::string &head, hipStream_t s) {
+  const int s1 = gemm_f16x2_splits(n, pl->inter, pl->fcsize / 16);
+  TT_TIMED(pl, "head.lin1", s, launch_gemm_f16x2(pl->feat, pl->w1f, pl->part, n, pl->inter, pl->fcsize, s1, s));
+  TT_TIMED(pl, polynomial ? "head.bn_poly" : "head.bn", s,
+           launch_head_mid(pl->part, s1, pl->bn_scale, pl->bn_shift, pl->mid_frag, n, pl->inter, polynomial, s));
+  TT_TIMED(pl, "head.lin2", s,
+           launch_lin2_f16x2(pl->mid_frag, pl->w2f, (const float *)pl->tensors[head + ".lin2.bias"].dev, pl->lin2_inv, logits, n,
+                             pl->n_classes, pl->inter, s));
+  return TTNET_OK;
+}
+
 // vAlexnet: block + Flatten + Classifier_scale from the stem bits in x_rp[0]
 int run_va_tail(ttnet_plan *pl, int n, float *logits, hipStream_t s) {
   MultiHead &mh = pl->blocks[0];
   TT_TIMED(pl, "va.block", s, launch_va_block(pl->x_rp[0], mh.c1.table, mh.c2.table, mh.c3.table, pl->va_y, n, s));
   TT_TIMED(pl, "va.flatten", s, launch_va_feat(pl->va_y, pl->feat, n, s));
-  const int s1 = gemm_f16x2_splits(n, pl->inter, pl->fcsize / 16);
-  TT_TIMED(pl, "head.lin1", s, launch_gemm_f16x2(pl->feat, pl->w1f, pl->part, n, pl->inter, pl->fcsize, s1, s));
-  TT_TIMED(pl, "head.bn", s, launch_head_mid(pl->part, s1, pl->bn_scale, pl->bn_shift, pl->mid, n, pl->inter, 0, s));
-  const int s2 = gemm_splits(n, pl->n_classes, pl->inter);
-  TT_TIMED(pl, "head.lin2", s,
-           launch_gemm_nt_splitk(pl->mid, (const float *)pl->tensors["features.7.lin2.weight"].dev, pl->part, n,
-                                 pl->n_classes, pl->inter, s2, s));
-  TT_TIMED(pl, "head.bias", s,
-           launch_head_out(pl->part, s2, (const float *)pl->tensors["features.7.lin2.bias"].dev, logits, n,
-                           pl->n_classes, s));
+  TT_TRY(run_head(pl, n, logits, 0, "features.7", s));
   pl->last_n = n;
   return TTNET_OK;
 }
@@ -635,16 +648,7 @@ int run_from_blocks(ttnet_plan *pl, int n, float *logits, hipStream_t s) {
       TT_TIMED(pl, "gate_last", s, launch_gate_last(a, (const float *)mh.cf.table, pl->feat, s));
     }
   }
-  const int s1 = gemm_f16x2_splits(n, pl->inter, pl->fcsize / 16);
-  TT_TIMED(pl, "head.lin1", s, launch_gemm_f16x2(pl->feat, pl->w1f, pl->part, n, pl->inter, pl->fcsize, s1, s));
-  TT_TIMED(pl, "head.bn_poly", s, launch_head_mid(pl->part, s1, pl->bn_scale, pl->bn_shift, pl->mid, n, pl->inter, 1, s));
-  const int s2 = gemm_splits(n, pl->n_classes, pl->inter);
-  TT_TIMED(pl, "head.lin2", s,
-           launch_gemm_nt_splitk(pl->mid, (const float *)pl->tensors[pl->head + ".lin2.weight"].dev, pl->part, n,
-                                 pl->n_classes, pl->inter, s2, s));
-  TT_TIMED(pl, "head.bias", s,
-           launch_head_out(pl->part, s2, (const float *)pl->tensors[pl->head + ".lin2.bias"].dev, logits, n,
-                           pl->n_classes, s));
+  TT_TRY(run_head(pl, n, logits, 1, pl->head, s));
   pl->last_n = n;
   return TTNET_OK;
 }
@@ -779,6 +783,7 @@ int ttnet_plan_finalize(ttnet_plan *pl, void *stream) {
     TT_TRY(upload_f32(pl->bn_shift, sh));
     TT_TRY(launch_split_to_frag((const float *)pl->tensors["features.7.lin1.weight"].dev, pl->w1f, pl->inter, pl->fcsize, 128, ws1,
                                 s));
+    TT_TRY(prepare_lin2(pl, "features.7.lin2.weight", s));
     TT_HIP(hipStreamSynchronize(s));
     for (BlockTT *b : all_block_tts(pl)) {
       if (b->user_table) continue;
@@ -819,6 +824,7 @@ int ttnet_plan_finalize(ttnet_plan *pl, void *stream) {
     TT_TRY(launch_permute_lin1((const float *)pl->tensors[pl->head + ".lin1.weight"].dev, pl->w1p, pl->inter,
                                pl->featC / 16, pl->featPP, s));
     TT_TRY(launch_split_to_frag(pl->w1p, pl->w1f, pl->inter, pl->fcsize, (pl->inter + 127) / 128 * 128, ws1, s));
+    TT_TRY(prepare_lin2(pl, pl->head + ".lin2.weight", s));
   }
   TT_HIP(hipStreamSynchronize(s));
   for (auto &mh : pl->blocks)

@@ -205,17 +205,18 @@ int launch_frag_to_reference_order(const void *af, float *out, int n, int G, int
 int gemm_f16x2_splits(int M, int N, int KS);
 int launch_gemm_f16x2(const void *Af, const void *Bf, float *part, int M, int N, int K, int splits, hipStream_t s);
 size_t frag_elems(int rows, int K);
-int launch_split_to_frag(const float *src, void *dst, int R, int K, int rows_padded, float prescale, hipStream_t s);
+// src [R][ld] (ld = 0: K) -> split planes with K (a multiple of 16) columns, columns >= kvalid (0: K) zero
+int launch_split_to_frag(const float *src, void *dst, int R, int K, int rows_padded, float prescale, hipStream_t s, int ld = 0,
+                         int kvalid = 0);
 
 // head.hip
-// C[M][N] (+)= A[M][K] * B[N][K]^T as split-K slabs: part[S][M][N]
-int launch_gemm_nt_splitk(const float *A, const float *B, float *part, int M, int N, int K, int splits,
-                          hipStream_t s);
-// z = sum_s part; z = z*scale+shift; out = 0.47+0.5z+0.09z^2   (Classifier_scale middle)
-int launch_head_mid(const float *part, int splits, const float *scale, const float *shift, float *out, int M,
-                    int N, int polynomial, hipStream_t s);
-// out = sum_s part + bias
-int launch_head_out(const float *part, int splits, const float *bias, float *out, int M, int N, hipStream_t s);
+// z = sum_s part; z = z*scale+shift; y = 0.47+0.5z+0.09z^2 (Classifier_scale middle), written as lin2's
+// split A operand: fragment order, rows = images (allocate padded to 64), ceil(N/16) k-steps
+int launch_head_mid(const float *part, int splits, const float *scale, const float *shift, void *mid_frag, int M, int N,
+                    int polynomial, hipStream_t s);
+// logits[M][N] = mid[M][K] * W2[N][K]^T * inv + bias on split operands (w2f rows padded to 64)
+int launch_lin2_f16x2(const void *mid_frag, const void *w2f, const float *bias, float inv, float *out, int M, int N, int K,
+                      hipStream_t s);
 // W1p[o][(g*PP+pp)*16+k] = W1[o][(16g+k)*PP+pp]
 int launch_permute_lin1(const float *w1, float *w1p, int O, int G, int PP, hipStream_t s);
 
