@@ -104,7 +104,7 @@ struct ttnet_plan {
 
   // stem
   uint16_t *stem_wt = nullptr;      // fp16 x 2 split weights, fragment order
-  float *stem_scale = nullptr, *stem_shift = nullptr;
+  float *stem_init = nullptr;       // accumulator start values (folded BN shift), 64 floats
   // activations: x_rp[i] / x_cp[i] = input of block i
   std::vector<uint64_t *> x_rp;
   std::vector<uint16_t *> x_cp;
@@ -398,8 +398,7 @@ int allocate(ttnet_plan *pl) {
     return TTNET_OK;
   }
   TT_TRY(dev_alloc(pl, &pl->stem_wt, stem_split_weights_elems(), false));
-  TT_TRY(dev_alloc(pl, &pl->stem_scale, pl->p, false));
-  TT_TRY(dev_alloc(pl, &pl->stem_shift, pl->p, false));
+  TT_TRY(dev_alloc(pl, &pl->stem_init, 64, false));
   pl->x_rp.resize(pl->blocks.size());
   pl->x_cp.resize(pl->blocks.size());
   for (size_t i = 0; i < pl->blocks.size(); ++i) {
@@ -794,18 +793,18 @@ int ttnet_plan_finalize(ttnet_plan *pl, void *stream) {
     pl->finalized = true;
     return TTNET_OK;
   }
-  // stem: weights split into two prescaled fp16 planes in MFMA fragment order; BN folded to fp32 scale/shift
+  // stem: BN scale folded into the weights, which are split into two prescaled fp16 planes in MFMA
+  // fragment order; BN shift as the accumulator start value
   {
     std::vector<float> w;
     TT_TRY(fetch(pl->tensors["features.1.weight"], w));
     std::vector<uint16_t> wf(stem_split_weights_elems());
-    const double prescale = stem_split_weights(w.data(), pl->p, wf.data());
-    TT_HIP(hipMemcpy(pl->stem_wt, wf.data(), wf.size() * 2, hipMemcpyHostToDevice));
     std::vector<double> sc, sh;
     TT_TRY(fold_bn(pl, "features.2", sc, sh));
-    for (double &v : sc) v /= prescale;          // power of two: exact
-    TT_TRY(upload_f32(pl->stem_scale, sc));
-    TT_TRY(upload_f32(pl->stem_shift, sh));
+    float init[64];
+    stem_split_weights(w.data(), sc.data(), sh.data(), pl->p, wf.data(), init);
+    TT_HIP(hipMemcpy(pl->stem_wt, wf.data(), wf.size() * 2, hipMemcpyHostToDevice));
+    TT_HIP(hipMemcpy(pl->stem_init, init, sizeof(init), hipMemcpyHostToDevice));
   }
   for (auto &mh : pl->blocks)
     for (BlockTT *b : {&mh.c1, &mh.c2, &mh.c3, &mh.cf}) TT_TRY(build_table(pl, *b, s));
@@ -850,7 +849,7 @@ int ttnet_forward(ttnet_plan *pl, const float *x_dev, int64_t n, float *logits_d
     return run_va_tail(pl, (int)n, logits_dev, s);
   }
   TT_TIMED(pl, "stem", s,
-           launch_stem(x_dev, pl->stem_wt, pl->stem_scale, pl->stem_shift, pl->x_rp[0], pl->full ? nullptr : pl->x_cp[0], (int)n,
+           launch_stem(x_dev, pl->stem_wt, pl->stem_init, pl->x_rp[0], pl->full ? nullptr : pl->x_cp[0], (int)n,
                        pl->p, s));
   return run_from_blocks(pl, (int)n, logits_dev, s);
 }

@@ -33,6 +33,7 @@
 #include <string.h>
 
 #include <cmath>
+#include <vector>
 
 #include "ttnet_common.h"
 
@@ -45,42 +46,70 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int SR = 8;                  // output rows per workgroup
 constexpr int TR = 2 * SR + 5;         // pooled rows in the tile
-constexpr int TW = 120;                // tile row pitch in elements (118 used)
+constexpr int TW = 120;                // tile row width in elements (118 used)
 constexpr int KSTEPS = 11;             // 22 (c,kh) rows (21 + one zero row), two per MFMA
 constexpr int NT = SR * 56 / 32;       // 14 N-tiles of 32 pixels
-constexpr int PLANE = 3 * TR * TW;     // elements per fp16 plane
-
 constexpr int NPL = SPLIT_PLANES;      // fp16 planes per operand
+constexpr int ROWP = NPL * TW;         // LDS pitch of a tile row: [plane 0: TW][plane 1: TW], so that one
+                                       // address register reaches both planes of a fragment (ds_read2 offsets)
+constexpr int TILE = 3 * TR * ROWP;    // elements per tile buffer
 constexpr float X_PRESCALE = ACT_PRESCALE;
 
 constexpr int CONS_WAVES = 8, PROD_WAVES = 4, STEM_THREADS = 64 * (CONS_WAVES + PROD_WAVES);
 constexpr int UNITS = NT * 2;          // (N-tile, M-tile) pairs of one item: 28
 constexpr int UPW = (UNITS + CONS_WAVES - 1) / CONS_WAVES;   // units per consumer wave: 4 (waves 4-7: 3)
 
+// Four ballots (accumulator registers R0 .. R0+3) at once: lane R0+i of (klo,khi) := ballot i, and
+// the ballots' own lane bits are shifted into cw, highest register first (cw = cw*2 + bit: the
+// carry-in of v_addc is the ballot).  One s_nop covers the VALU -> SGPR -> VALU wait states that
+// hipcc does not insert inside an asm statement.
+template <int R0>
+__device__ inline void ballots4(uint32_t &klo, uint32_t &khi, uint32_t &cw, uint64_t m0, uint64_t m1, uint64_t m2, uint64_t m3) {
+  asm("s_nop 1\n\t"
+      "v_writelane_b32 %0, %3, %15\n\tv_writelane_b32 %1, %4, %15\n\t"
+      "v_writelane_b32 %0, %5, %16\n\tv_writelane_b32 %1, %6, %16\n\t"
+      "v_writelane_b32 %0, %7, %17\n\tv_writelane_b32 %1, %8, %17\n\t"
+      "v_writelane_b32 %0, %9, %18\n\tv_writelane_b32 %1, %10, %18\n\t"
+      "v_addc_co_u32 %2, vcc, %2, %2, %14\n\t"
+      "v_addc_co_u32 %2, vcc, %2, %2, %13\n\t"
+      "v_addc_co_u32 %2, vcc, %2, %2, %12\n\t"
+      "v_addc_co_u32 %2, vcc, %2, %2, %11"
+      : "+v"(klo), "+v"(khi), "+v"(cw)
+      : "s"((uint32_t)m0), "s"((uint32_t)(m0 >> 32)), "s"((uint32_t)m1), "s"((uint32_t)(m1 >> 32)), "s"((uint32_t)m2),
+        "s"((uint32_t)(m2 >> 32)), "s"((uint32_t)m3), "s"((uint32_t)(m3 >> 32)), "s"(m0), "s"(m1), "s"(m2), "s"(m3), "n"(R0),
+        "n"(R0 + 1), "n"(R0 + 2), "n"(R0 + 3)
+      : "vcc");
+}
+
 // Persistent producer / consumer kernel.  One workgroup per CU walks items (image, block of SR
 // output rows).  Producer waves stream the raw float32 rows from HBM, pool them and write the
 // two fp16 planes of the NEXT item's tile into the other half of an LDS double buffer;
-// consumer waves run the MFMAs and the BN/sign/pack epilogue of the CURRENT item.  One
-// workgroup barrier per item.  (With build -> MFMA -> epilogue serial inside a workgroup the
-// kernel idled the matrix pipe and HBM alternately: 116 us at B = 256 against a 43 us MFMA
-// floor.)  Consumer wave w owns units w, w+8, ...: all of one M-tile (u & 1 = w & 1), so a wave
-// needs only that M-tile's weight fragments; waves w and w+4 share a SIMD and carry 4 + 3 units.
+// consumer waves run the MFMAs and the sign/pack epilogue of the CURRENT item.  One workgroup
+// barrier per item.  Consumer wave w owns units w, w+8, ...: all of one M-tile (u & 1 = w & 1), so
+// a wave needs only that M-tile's weight fragments; waves w and w+4 share a SIMD and carry 4 + 3
+// units.  BatchNorm is folded: its scale into the weights (host), its shift into the initial
+// value of the accumulators, so the epilogue is the sign test alone.
+//
+// Every vector instruction counts here (MFMA and VALU time add up on a SIMD): wave-uniform
+// indices are forced into SGPRs, border handling is a clamp of the load address plus a 0/4
+// multiplier instead of per-element selects, and everything that does not depend on the item is
+// computed once.
 __global__ __launch_bounds__(STEM_THREADS) void stem_pc_kernel(const float *__restrict__ x, const uint4 *__restrict__ wfrag,
-                                                               const float *__restrict__ scale,
-                                                               const float *__restrict__ shift, uint64_t *__restrict__ rp,
+                                                               const float *__restrict__ init, uint64_t *__restrict__ rp,
                                                                uint16_t *__restrict__ cp, int p, int n_images) {
   extern __shared__ __align__(16) uint8_t smem[];
-  uint16_t *tiles = (uint16_t *)smem;                               // [2][NPL * PLANE] fp16
-  uint32_t(*stage)[64][NT + 2] = (uint32_t(*)[64][NT + 2])(smem + 2 * NPL * PLANE * 2);   // [2][64][NT+2]
-  float *s_scale = (float *)(smem + 2 * NPL * PLANE * 2 + 2 * 64 * (NT + 2) * 4), *s_shift = s_scale + 64;
+  uint16_t *tiles = (uint16_t *)smem;                               // [2][TILE] fp16
+  uint32_t(*stage)[64][NT + 2] = (uint32_t(*)[64][NT + 2])(smem + 2 * TILE * 2);   // [2][64][NT+2]
+  float *s_init = (float *)(smem + 2 * TILE * 2 + 2 * 64 * (NT + 2) * 4);          // [mtile][half][16] accumulator start values
   const int H = 224, W = 224;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const bool producer = wave >= CONS_WAVES;
   const int items = n_images * (56 / SR);
   const int my_items = (items - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
-  if (threadIdx.x < 64) {                               // channels >= p: zero weights, never stored
-    s_scale[threadIdx.x] = (int)threadIdx.x < p ? scale[threadIdx.x] : 0.f;
-    s_shift[threadIdx.x] = (int)threadIdx.x < p ? shift[threadIdx.x] : 0.f;
+  if (threadIdx.x < 64) {
+    // C/D layout of the 32x32 MFMA: row (channel within the M-tile) = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+    const int mm = threadIdx.x >> 5, hh = (threadIdx.x >> 4) & 1, r = threadIdx.x & 15;
+    s_init[threadIdx.x] = init[32 * mm + (r & 3) + 8 * (r >> 2) + 4 * hh];
   }
   if (threadIdx.x < 128) {
     stage[threadIdx.x >> 6][threadIdx.x & 63][NT] = 0;
@@ -88,46 +117,59 @@ __global__ __launch_bounds__(STEM_THREADS) void stem_pc_kernel(const float *__re
   }
 
   // ---- producer side -----------------------------------------------------------------------
-  auto build_tile = [&](int item, uint16_t *tile) {
+  // tile column px = pooled image column px - 3; a lane handles px = lane and px = lane + 64
+  int colc[2];
+  float colm[2];
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int ix = lane + 64 * k - 3;
+    colc[k] = 2 * min(max(ix, 0), 111);
+    colm[k] = (ix >= 0 && ix < 112) ? 0.25f * X_PRESCALE : 0.0f;     // average of four, prescale; 0 in the padding
+  }
+  // pooled tile row r = pooled image row 2*oy0 - 3 + r; a producer wave owns the (c, r) rows pw,
+  // pw+4, ...  All global loads of an item are issued at once, one item ahead: they are in flight
+  // across the workgroup barrier and while the row words of the previous item are emitted, so
+  // the HBM latency is not on the per-item critical path (a producer that loads, waits and
+  // splits in turn needs 15.5 k cycles per item against 12 k for the consumers).
+  constexpr int RPW = (3 * TR + PROD_WAVES - 1) / PROD_WAVES;        // rows per producer wave: 16
+  float2 ra[RPW][2], rb[RPW][2];
+  auto issue_loads = [&](int item) {
     const int n = item / (56 / SR), oy0 = (item % (56 / SR)) * SR;
     const int pw = wave - CONS_WAVES;                   // 0..3
-    // pooled tile row r = pooled image row 2*oy0 - 3 + r; a wave owns (c, r) rows pw, pw+4, ... and
-    // walks them in batches of B rows with every global load of the batch in flight
-    constexpr int B = 8, ROWS_PER_WAVE = (3 * TR + PROD_WAVES - 1) / PROD_WAVES;
-    for (int b0 = 0; b0 < ROWS_PER_WAVE; b0 += B) {
-      float2 ra[B][2], rb[B][2];
 #pragma unroll
-      for (int bi = 0; bi < B; ++bi) {
-        const int cr = pw + PROD_WAVES * (b0 + bi);
+    for (int bi = 0; bi < RPW; ++bi) {
+      const int cr = pw + PROD_WAVES * bi;              // wave-uniform
+      const int c = cr / TR, r = cr - c * TR;
+      const int iy = 2 * oy0 - 3 + r;
+      const bool row_ok = cr < 3 * TR && iy >= 0 && iy < 112;
+      const float *src_row = x + (((size_t)n * 3 + (row_ok ? c : 0)) * H + 2 * (row_ok ? iy : 0)) * W;
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        ra[bi][k] = *(const float2 *)(src_row + colc[k]);
+        rb[bi][k] = *(const float2 *)(src_row + W + colc[k]);
+      }
+    }
+  };
+  auto split_tile = [&](int item, uint16_t *tile) {
+    const int oy0 = (item % (56 / SR)) * SR;
+    const int pw = wave - CONS_WAVES;
+#pragma unroll
+    for (int bi = 0; bi < RPW; ++bi) {
+      const int cr = pw + PROD_WAVES * bi;
+      if (cr < 3 * TR) {
         const int c = cr / TR, r = cr - c * TR;
         const int iy = 2 * oy0 - 3 + r;
-        const bool row_ok = cr < 3 * TR && iy >= 0 && iy < 112;
-        const float *src_row = x + (((size_t)n * 3 + (row_ok ? c : 0)) * H + 2 * (row_ok ? iy : 0)) * W;
+        const float rowm = (iy >= 0 && iy < 112) ? 1.0f : 0.0f;      // wave-uniform
+        uint16_t *dst = tile + (c * TR + r) * ROWP + lane;
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
-          const int ix = lane + 64 * k - 3;
-          const bool ok = row_ok && ix >= 0 && ix < 112;
-          ra[bi][k] = ok ? *(const float2 *)(src_row + 2 * ix) : make_float2(0.f, 0.f);
-          rb[bi][k] = ok ? *(const float2 *)(src_row + W + 2 * ix) : make_float2(0.f, 0.f);
-        }
-      }
-#pragma unroll
-      for (int bi = 0; bi < B; ++bi) {
-        const int cr = pw + PROD_WAVES * (b0 + bi);
-        if (cr < 3 * TR) {
-          const int c = cr / TR, r = cr - c * TR;
-#pragma unroll
-          for (int k = 0; k < 2; ++k) {
-            const int px = lane + 64 * k;
-            if (px < TW) {
-              // pooled value exactly as the reference forms it (x 0.25), then the exact x16 prescale
-              const float v = ((((ra[bi][k].x + ra[bi][k].y) + rb[bi][k].x) + rb[bi][k].y) * 0.25f) * X_PRESCALE;
-              const _Float16 h1 = (_Float16)v;
-              const _Float16 h2 = (_Float16)(v - (float)h1);
-              const int e = (c * TR + r) * TW + px;
-              tile[e] = __builtin_bit_cast(uint16_t, h1);
-              tile[PLANE + e] = __builtin_bit_cast(uint16_t, h2);
-            }
+          if (lane + 64 * k < TW) {
+            // pooled value exactly as the reference forms it (x 0.25), times the exact prescale
+            const float v = (((ra[bi][k].x + ra[bi][k].y) + rb[bi][k].x) + rb[bi][k].y) * (colm[k] * rowm);
+            const _Float16 h1 = (_Float16)v;
+            const _Float16 h2 = (_Float16)(v - (float)h1);
+            dst[64 * k] = __builtin_bit_cast(uint16_t, h1);
+            dst[64 * k + TW] = __builtin_bit_cast(uint16_t, h2);
           }
         }
       }
@@ -150,21 +192,22 @@ __global__ __launch_bounds__(STEM_THREADS) void stem_pc_kernel(const float *__re
   // ---- consumer side -----------------------------------------------------------------------
   const int h = lane >> 5, col = lane & 31;
   const int m = wave & 1;                                // this wave's M-tile (consumers only)
-  auto compute_item = [&](int item, const uint16_t *tile, uint32_t (*st)[NT + 2]) {
-    const int n = item / (56 / SR), oy0 = (item % (56 / SR)) * SR;
-    int pixoff[UPW];
+  // per unit, independent of the item: dword offset of the lane's pixel in the tile, and its
+  // offset in a channel-word plane
+  int pixdw[UPW], cpoff[UPW];
 #pragma unroll
-    for (int i = 0; i < UPW; ++i) {
-      const int u = wave + CONS_WAVES * i, t = u >> 1;
-      const int pp = 32 * (u < UNITS ? t : 0) + col;
-      const int oyl = pp / 56, ox = pp - 56 * oyl;
-      pixoff[i] = 2 * oyl * TW + 2 * ox;
-    }
+  for (int i = 0; i < UPW; ++i) {
+    const int u = wave + CONS_WAVES * i, t = u >> 1;
+    const int pp = 32 * (u < UNITS ? t : 0) + col;
+    const int oyl = pp / 56, ox = pp - 56 * oyl;
+    pixdw[i] = (2 * oyl * ROWP + 2 * ox) >> 1;
+    cpoff[i] = oyl * 56 + ox;
+  }
+  auto compute_item = [&](int item, const uint16_t *tile, uint32_t (*st)[NT + 2], const f32x16 &start) {
+    const int n = item / (56 / SR), oy0 = (item % (56 / SR)) * SR;
     f32x16 acc[UPW];
 #pragma unroll
-    for (int i = 0; i < UPW; ++i)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    for (int i = 0; i < UPW; ++i) acc[i] = start;
     const uint32_t *tile32 = (const uint32_t *)tile;
     // weights in fragment order [ks][plane][mtile][lane] x 16 bytes, fetched one k-step ahead
     uint4 aw_next[NPL];
@@ -182,55 +225,55 @@ __global__ __launch_bounds__(STEM_THREADS) void stem_pc_kernel(const float *__re
       int R = 2 * ks + h;                    // (c,kh) row of this half-wave's 8 k values
       if (R > 20) R = 20;                    // zero-weight pad row: any finite data
       const int c = (R * 37) >> 8, kh = R - 7 * c;
-      const int rowoff = (c * TR + kh) * TW;
+      const uint32_t *rowp = tile32 + (c * TR + kh) * (ROWP / 2);
       const f16x8 w1 = __builtin_bit_cast(f16x8, aw[0]), w2 = __builtin_bit_cast(f16x8, aw[1]);
+      // the B fragments of unit i+1 are read from LDS while the three MFMAs of unit i run
+      // (two register sets; a wave that reads and multiplies in turn idles the matrix pipe for
+      // an LDS round trip per unit)
+      auto read_b = [&](int i, uint4 (&v)[NPL]) {
+        const uint32_t *q = rowp + pixdw[i];
+        v[0].x = q[0]; v[0].y = q[1]; v[0].z = q[2]; v[0].w = q[3];
+        v[1].x = q[TW / 2]; v[1].y = q[TW / 2 + 1]; v[1].z = q[TW / 2 + 2]; v[1].w = q[TW / 2 + 3];
+      };
+      uint4 bq[2][NPL];
+      read_b(0, bq[0]);
 #pragma unroll
       for (int i = 0; i < UPW; ++i) {
+        if (i + 1 < UPW) read_b(i + 1, bq[(i + 1) & 1]);   // a 4th unit that does not exist repeats unit 0's address
+        __builtin_amdgcn_sched_barrier(0);                  // keep the reads ahead of the MFMAs
         if (wave + CONS_WAVES * i < UNITS) {   // wave-uniform
-          const int e = (rowoff + pixoff[i]) >> 1;       // dword index: both terms are even
-          f16x8 bx[NPL];
-#pragma unroll
-          for (int pl = 0; pl < NPL; ++pl) {
-            uint4 v;
-            v.x = tile32[pl * (PLANE / 2) + e];
-            v.y = tile32[pl * (PLANE / 2) + e + 1];
-            v.z = tile32[pl * (PLANE / 2) + e + 2];
-            v.w = tile32[pl * (PLANE / 2) + e + 3];
-            bx[pl] = __builtin_bit_cast(f16x8, v);
-          }
+          const f16x8 x1 = __builtin_bit_cast(f16x8, bq[i & 1][0]), x2 = __builtin_bit_cast(f16x8, bq[i & 1][1]);
           f32x16 a = acc[i];
-          a = __builtin_amdgcn_mfma_f32_32x32x16_f16(w2, bx[0], a, 0, 0, 0);
-          a = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1, bx[1], a, 0, 0, 0);
-          a = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1, bx[0], a, 0, 0, 0);
+          a = __builtin_amdgcn_mfma_f32_32x32x16_f16(w2, x1, a, 0, 0, 0);
+          a = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1, x2, a, 0, 0, 0);
+          a = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1, x1, a, 0, 0, 0);
           acc[i] = a;
         }
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
-    // epilogue: BN + sign.  C/D layout of the 32x32 MFMA: column = lane&31 (pixel),
-    // row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) (channel within the M-tile).
-    const float *sc_l = s_scale + m * 32 + 4 * h, *sh_l = s_shift + m * 32 + 4 * h;   // + (r&3) + 8*(r>>2)
+    // epilogue: sign + pack.  C/D layout of the 32x32 MFMA: column = lane&31 (pixel),
+    // row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) (channel within the M-tile).  The ballot of
+    // register r is the row-word piece of two channels (lanes 0-31 / 32-63) over 32 pixels; the
+    // lane's own bits, collected over the registers, are its pixel's channel-word nibbles.
 #pragma unroll
     for (int i = 0; i < UPW; ++i) {
       const int u = wave + CONS_WAVES * i;
       if (u >= UNITS) continue;
       const int t = u >> 1;
-      const int pp = 32 * t + col;
-      const int oyl = pp / 56, ox = pp - 56 * oyl;
       uint32_t klo = 0, khi = 0;             // lane r keeps the ballot of accumulator register r
-      uint32_t pw0 = 0, pw1 = 0;
-      static_for<0, 16>([&](auto rr) {
-        constexpr int r = decltype(rr)::value;
-        const float pre = fmaf(acc[i][r], sc_l[(r & 3) + 8 * (r >> 2)], sh_l[(r & 3) + 8 * (r >> 2)]);
-        const bool bit = pre >= 0.0f;
-        writelane64<r>(klo, khi, __ballot(bit));
-        constexpr uint32_t kbit = (r & 3) + 8 * ((r >> 2) & 1);
-        if constexpr (r < 8) pw0 |= bit ? (1u << kbit) : 0u;
-        else pw1 |= bit ? (1u << kbit) : 0u;
-      });
-      uint32_t pw = (pw0 | (pw1 << 16)) << (4 * h);
+      uint32_t cw0 = 0, cw1 = 0;             // bit (r&3) + 4*((r>>2)&1) of cw0 (r < 8) / cw1 (r >= 8)
+      auto bal = [&](int r) { return __ballot(acc[i][r] >= 0.0f); };
+      ballots4<12>(klo, khi, cw1, bal(12), bal(13), bal(14), bal(15));
+      ballots4<8>(klo, khi, cw1, bal(8), bal(9), bal(10), bal(11));
+      ballots4<4>(klo, khi, cw0, bal(4), bal(5), bal(6), bal(7));
+      ballots4<0>(klo, khi, cw0, bal(0), bal(1), bal(2), bal(3));
+      // channel word bit of register r: (r&3) + 8*((r>>2)&1) + 4*h within the 16-channel group r>>3
+      uint32_t pw = ((cw0 & 15u) | ((cw0 & 0xF0u) << 4)) | (((cw1 & 15u) | ((cw1 & 0xF0u) << 4)) << 16);
+      pw <<= 4 * h;
       pw |= (uint32_t)__shfl_xor((int)pw, 32);
       const int q = 2 * m + h;               // half-wave 0 stores group 2m, half-wave 1 group 2m+1
-      if (cp) cp[(((size_t)n * 4 + q) * 56 + oy0 + oyl) * 56 + ox] = (uint16_t)(h ? (pw >> 16) : pw);
+      if (cp) cp[((size_t)n * 4 + q) * (56 * 56) + oy0 * 56 + cpoff[i]] = (uint16_t)(h ? (pw >> 16) : pw);
       if (lane < 16) {                        // lanes 0-31 of the ballot: channel chl, lanes 32-63: chl + 4
         const int chl = m * 32 + (lane & 3) + 8 * (lane >> 2);
         st[chl][t] = klo;
@@ -240,28 +283,41 @@ __global__ __launch_bounds__(STEM_THREADS) void stem_pc_kernel(const float *__re
   };
 
   // ---- pipeline --------------------------------------------------------------------------------
-  __syncthreads();
-  if (producer && my_items > 0) build_tile(blockIdx.x, tiles);
-  __syncthreads();
-  for (int j = 0; j < my_items; ++j) {
-    const int item = blockIdx.x + j * gridDim.x;
-    if (producer) {
-      if (j > 0) emit_rows(item - gridDim.x, stage[(j - 1) & 1]);
-      if (j + 1 < my_items) build_tile(item + gridDim.x, tiles + ((j + 1) & 1) * NPL * PLANE);
-    } else {
-      compute_item(item, tiles + (j & 1) * NPL * PLANE, stage[j & 1]);
-    }
+  // Period j: consumers work on item j (tile buffer j&1); producers emit the row words of item
+  // j-1, split item j+1 (loaded during period j-1) into the other buffer and issue the loads of
+  // item j+2.  Each role runs its own loop with the same my_items + 2 barriers.
+  const int g = gridDim.x, first = blockIdx.x;
+  if (producer) {
+    if (my_items > 0) issue_loads(first);
     __syncthreads();
+    if (my_items > 0) split_tile(first, tiles);
+    if (my_items > 1) issue_loads(first + g);
+    __syncthreads();
+    for (int j = 0; j < my_items; ++j) {
+      const int item = first + j * g;
+      if (j > 0) emit_rows(item - g, stage[(j - 1) & 1]);
+      if (j + 1 < my_items) split_tile(item + g, tiles + ((j + 1) & 1) * TILE);
+      if (j + 2 < my_items) issue_loads(item + 2 * g);
+      __syncthreads();
+    }
+    if (my_items > 0) emit_rows(first + (my_items - 1) * g, stage[(my_items - 1) & 1]);
+  } else {
+    __syncthreads();
+    __syncthreads();
+    const f32x16 start = *(const f32x16 *)(s_init + (m * 2 + h) * 16);
+    for (int j = 0; j < my_items; ++j) {
+      compute_item(first + j * g, tiles + (j & 1) * TILE, stage[j & 1], start);
+      __syncthreads();
+    }
   }
-  if (producer && my_items > 0) emit_rows(blockIdx.x + (my_items - 1) * gridDim.x, stage[(my_items - 1) & 1]);
 }
 
 }  // namespace
 
 // Host side of the operand split: w [64][3][7][7] float32 -> fragment-ordered fp16 planes
 // [ks][plane][mtile][lane][8]: lane l of M-tile m holds channel 32m + (l&31), k = 16ks + 8(l>>5) + j,
-// k = ((c*7 + kh)*8 + kw); kw = 7 and the 22nd (c,kh) row carry zero weights.  Returns the
-// total power-of-two prescale (weights x activations) the caller divides out of the BN scale.
+// k = ((c*7 + kh)*8 + kw); kw = 7 and the 22nd (c,kh) row carry zero weights.  init[64]: the
+// accumulator start values (the folded BN shift in the prescaled unit).
 static uint16_t f32_to_f16_rne(float f) {
   uint32_t u;
   memcpy(&u, &f, 4);
@@ -282,36 +338,41 @@ static float f16_to_f32(uint16_t h) {
   return (h & 0x8000u) ? -mag : mag;
 }
 
-float stem_split_weights(const float *w, int p, uint16_t *out) {
-  const float ws = weight_prescale(w, (size_t)p * 147);
+void stem_split_weights(const float *w, const double *scale, const double *shift, int p, uint16_t *out, float *init) {
+  // BatchNorm scale folded into the weights (float32 product, like any other float32 rounding of
+  // the reference's conv + BN chain), shift into the accumulator start value
+  std::vector<float> wf((size_t)p * 147);
+  for (int ch = 0; ch < p; ++ch)
+    for (int i = 0; i < 147; ++i) wf[(size_t)ch * 147 + i] = (float)((double)w[(size_t)ch * 147 + i] * scale[ch]);
+  const float ws = weight_prescale(wf.data(), wf.size());
+  for (int ch = 0; ch < 64; ++ch) init[ch] = ch < p ? (float)(shift[ch] * (double)ws * (double)X_PRESCALE) : -1.0f;
   for (int ks = 0; ks < KSTEPS; ++ks)
     for (int m = 0; m < 2; ++m)
       for (int l = 0; l < 64; ++l)
         for (int j = 0; j < 8; ++j) {
           const int ch = 32 * m + (l & 31), R = 2 * ks + (l >> 5), kw = j;
           float v = 0.f;
-          if (ch < p && R < 21 && kw < 7) v = w[(size_t)ch * 147 + R * 7 + kw] * ws;     // R = c*7 + kh
+          if (ch < p && R < 21 && kw < 7) v = wf[(size_t)ch * 147 + R * 7 + kw] * ws;     // R = c*7 + kh
           const uint16_t h1 = f32_to_f16_rne(v);
           const uint16_t h2 = f32_to_f16_rne(v - f16_to_f32(h1));
           const uint16_t parts[NPL] = {h1, h2};
           for (int pl = 0; pl < NPL; ++pl) out[((((size_t)ks * NPL + pl) * 2 + m) * 64 + l) * 8 + j] = parts[pl];
         }
-  return ws * X_PRESCALE;
 }
 
 size_t stem_split_weights_elems() { return (size_t)KSTEPS * NPL * 2 * 64 * 8; }
 
-int launch_stem(const float *x, const void *wfrag, const float *scale, const float *shift, uint64_t *rp,
-                uint16_t *cp, int n, int p, hipStream_t s) {
+int launch_stem(const float *x, const void *wfrag, const float *init, uint64_t *rp, uint16_t *cp, int n, int p,
+                hipStream_t s) {
   if (p < 1 || p > 64 || (cp && p != 64)) {
     set_error("stem: p=%d outside [1,64] (channel words need p = 64)", p);
     return TTNET_E_UNSUPPORTED;
   }
-  const size_t lds = (size_t)2 * NPL * PLANE * 2 + (size_t)2 * 64 * (NT + 2) * 4 + 128 * 4;
+  const size_t lds = (size_t)2 * TILE * 2 + (size_t)2 * 64 * (NT + 2) * 4 + 64 * 4;
   TT_HIP(hipFuncSetAttribute((const void *)stem_pc_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const int items = n * (56 / SR);
-  hipLaunchKernelGGL(stem_pc_kernel, dim3(std::min(items, 256)), dim3(STEM_THREADS), lds, s, x, (const uint4 *)wfrag, scale,
-                     shift, rp, cp, p, n);
+  hipLaunchKernelGGL(stem_pc_kernel, dim3(std::min(items, 256)), dim3(STEM_THREADS), lds, s, x, (const uint4 *)wfrag, init, rp,
+                     cp, p, n);
   TT_HIP(hipGetLastError());
   return TTNET_OK;
 }

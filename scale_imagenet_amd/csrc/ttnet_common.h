@@ -129,11 +129,11 @@ __device__ inline float load_feature(const uint16_t *feat_frag, int img, int KS,
 float weight_prescale(const float *w, size_t n);
 
 // stem.hip
-// wfrag: the conv weights split into two fp16 planes in MFMA fragment order (stem_split_weights,
-// which returns the power-of-two operand prescale to divide out of the BN scale)
-int launch_stem(const float *x, const void *wfrag, const float *scale, const float *shift, uint64_t *rp,
-                uint16_t *cp, int n, int p, hipStream_t s);
-float stem_split_weights(const float *w /*[p][3][7][7]*/, int p, uint16_t *out);
+// wfrag: the conv weights (BN scale folded in) split into two fp16 planes in MFMA fragment order;
+// init[64]: accumulator start values = the folded BN shift (both from stem_split_weights)
+int launch_stem(const float *x, const void *wfrag, const float *init, uint64_t *rp, uint16_t *cp, int n, int p, hipStream_t s);
+void stem_split_weights(const float *w /*[p][3][7][7]*/, const double *scale, const double *shift, int p, uint16_t *out,
+                        float *init /*[64]*/);
 size_t stem_split_weights_elems();
 
 // gate.hip
