@@ -12,7 +12,7 @@
 //        ([tile32][kstep16][plane][lane][8 fp16]) so that every global->LDS transfer and every
 //        LDS fragment read is a linear 1 KiB block.
 //   lin2 (K = 1000, padded to 1008) uses the same split operands in one small kernel
-//        (lin2_f16x2_kernel): 64x64 output tile per workgroup, K split over its 8 waves,
+//        (lin2_f16x2_kernel): 32x32 output tile per workgroup, K split over its 8 waves,
 //        partial tiles summed through LDS in wave order, bias fused.
 // M = images is small (256), so lin1's K is split across workgroups to fill the 256 CUs; the
 // partial slabs are summed in a fixed order by head_mid_kernel (bitwise reproducible, no float
@@ -213,32 +213,29 @@ __global__ void head_mid_kernel(const float *__restrict__ part, int splits, cons
 }
 
 // ---- lin2: out[M][N] = A[M][K] * B[N][K]^T * inv + bias, split operands in fragment order ----
-// A: [ceil(M/64)*2][KS][NP][64][8], B: [ceil(N/64)*2][KS][NP][64][8] (tile rows padded to 64).
-constexpr int L2_WAVES = 8, L2_STAGES = 4, L2_LDS = L2_WAVES * 4 * 16 * 64 * 4;
+// A: [ceil(M/32)][KS][NP][64][8], B: [ceil(N/32)][KS][NP][64][8].  One 32x32 output tile per
+// workgroup (256 workgroups at M = 256, N = 1000: the kernel is bound by how fast one CU can pull
+// its 2 x 126 KiB of fragments out of L2, so the tiles are small and spread over all CUs), K
+// split over the 8 waves, partial tiles summed through LDS in wave order, bias fused.
+constexpr int L2_WAVES = 8, L2_STAGES = 4, L2_LDS = L2_WAVES * 16 * 64 * 4;
 __global__ __launch_bounds__(64 * L2_WAVES) void lin2_f16x2_kernel(const uint4 *__restrict__ A, const uint4 *__restrict__ B,
                                                                    const float *__restrict__ bias, float inv,
                                                                    float *__restrict__ out, int M, int N, int KS) {
-  extern __shared__ __align__(16) float red[];          // [wave][tile][reg][lane]
+  __shared__ __align__(16) float red[L2_WAVES * 16 * 64];            // [wave][reg][lane]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int mt0 = blockIdx.y * 2, nt0 = blockIdx.x * 2;
-  f32x16 acc[2][2];
+  const int mt = blockIdx.y, nt = blockIdx.x;
+  f32x16 acc;
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
   const int nk = wave < KS ? (KS - wave + L2_WAVES - 1) / L2_WAVES : 0;      // this wave's k-steps: wave + 8 i
-  uint4 fa[L2_STAGES][2][NP], fb[L2_STAGES][2][NP];
-  auto load = [&](int i, uint4 (&a)[2][NP], uint4 (&b)[2][NP]) {
+  uint4 fa[L2_STAGES][NP], fb[L2_STAGES][NP];
+  auto load = [&](int i, uint4 (&a)[NP], uint4 (&b)[NP]) {
     const int ks = wave + L2_WAVES * i;
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-      for (int pl = 0; pl < NP; ++pl) {
-        a[t][pl] = A[(((size_t)(mt0 + t) * KS + ks) * NP + pl) * 64 + lane];
-        b[t][pl] = B[(((size_t)(nt0 + t) * KS + ks) * NP + pl) * 64 + lane];
-      }
+    for (int pl = 0; pl < NP; ++pl) {
+      a[pl] = A[(((size_t)mt * KS + ks) * NP + pl) * 64 + lane];
+      b[pl] = B[(((size_t)nt * KS + ks) * NP + pl) * 64 + lane];
+    }
   };
   static_for<0, L2_STAGES>([&](auto ss) {
     constexpr int sl = decltype(ss)::value;
@@ -248,36 +245,25 @@ __global__ __launch_bounds__(64 * L2_WAVES) void lin2_f16x2_kernel(const uint4 *
     static_for<0, L2_STAGES>([&](auto ss) {
       constexpr int sl = decltype(ss)::value;
       if (i0 + sl < nk) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-          for (int j = 0; j < 2; ++j) {
-            const f16x8 a0 = __builtin_bit_cast(f16x8, fa[sl][i][0]), a1 = __builtin_bit_cast(f16x8, fa[sl][i][1]);
-            const f16x8 b0 = __builtin_bit_cast(f16x8, fb[sl][j][0]), b1 = __builtin_bit_cast(f16x8, fb[sl][j][1]);
-            f32x16 c = acc[i][j];
-            c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b0, c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b1, c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b0, c, 0, 0, 0);
-            acc[i][j] = c;
-          }
+        const f16x8 a0 = __builtin_bit_cast(f16x8, fa[sl][0]), a1 = __builtin_bit_cast(f16x8, fa[sl][1]);
+        const f16x8 b0 = __builtin_bit_cast(f16x8, fb[sl][0]), b1 = __builtin_bit_cast(f16x8, fb[sl][1]);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b0, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b1, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b0, acc, 0, 0, 0);
         if (i0 + sl + L2_STAGES < nk) load(i0 + sl + L2_STAGES, fa[sl], fb[sl]);
       }
     });
   }
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) red[((wave * 4 + i * 2 + j) * 16 + r) * 64 + lane] = acc[i][j][r];
+  for (int r = 0; r < 16; ++r) red[(wave * 16 + r) * 64 + lane] = acc[r];
   __syncthreads();
-  for (int e = threadIdx.x; e < 4 * 16 * 64; e += 64 * L2_WAVES) {
+  for (int e = threadIdx.x; e < 16 * 64; e += 64 * L2_WAVES) {
     double sum = 0.0;
 #pragma unroll
-    for (int w = 0; w < L2_WAVES; ++w) sum += (double)red[w * (4 * 16 * 64) + e];      // wave order: reproducible
-    const int ln = e & 63, r = (e >> 6) & 15, t = e >> 10;
-    const int row = (mt0 + (t >> 1)) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (ln >> 5);
-    const int col = (nt0 + (t & 1)) * 32 + (ln & 31);
+    for (int w = 0; w < L2_WAVES; ++w) sum += (double)red[w * (16 * 64) + e];      // wave order: reproducible
+    const int ln = e & 63, r = e >> 6;
+    const int row = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * (ln >> 5);
+    const int col = nt * 32 + (ln & 31);
     if (row < M && col < N) out[(size_t)row * N + col] = (float)(sum * (double)inv + (double)bias[col]);
   }
 }
@@ -360,8 +346,7 @@ int launch_head_mid(const float *part, int splits, const float *scale, const flo
 int launch_lin2_f16x2(const void *mid_frag, const void *w2f, const float *bias, float inv, float *out, int M, int N, int K,
                       hipStream_t s) {
   const int KS = (K + 15) / 16;
-  TT_HIP(hipFuncSetAttribute((const void *)lin2_f16x2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, L2_LDS));
-  hipLaunchKernelGGL(lin2_f16x2_kernel, dim3((N + 63) / 64, (M + 63) / 64), dim3(64 * L2_WAVES), L2_LDS, s,
+  hipLaunchKernelGGL(lin2_f16x2_kernel, dim3((N + 31) / 32, (M + 31) / 32), dim3(64 * L2_WAVES), 0, s,
                      (const uint4 *)mid_frag, (const uint4 *)w2f, bias, inv, out, M, N, KS);
   TT_HIP(hipGetLastError());
   return TTNET_OK;
