@@ -95,7 +95,9 @@ int ttnet_plan_finalize(ttnet_plan *plan, void *stream);
  * `outputs = model(inputs)` at main.py:261 in eval mode under no_grad.
  *   x_dev      float32 [n,3,image_h,image_w] NCHW, contiguous, on the plan's device
  *   logits_dev float32 [n,n_classes]  (1000; 10 for TTNET_VALEXNET)
- * Asynchronous on `stream`. */
+ * Asynchronous on `stream`.  From the third call with the same n the launches are replayed from a
+ * hipGraph captured on a private stream (the input / logits pointers are patched per call);
+ * TTNET_NO_GRAPH=1 in the environment keeps plain launches.  Results are identical either way. */
 int ttnet_forward(ttnet_plan *plan, const float *x_dev, int64_t n, float *logits_dev, void *stream);
 
 /* Same, starting from the binarised stem output (features[3], netbin.py:193) given as
@@ -124,7 +126,8 @@ int ttnet_plan_set_table(ttnet_plan *plan, const char *name, const void *src_hos
 
 /* Integer facts about the plan: "fcsize", "n_classes", "n_state_tensors", "max_batch",
  * "near_ties:<block_tt name>" (entries with |pre-activation| < 1e-5 found while building
- * that table), "table_bytes", "workspace_bytes". */
+ * that table), "table_bytes", "workspace_bytes", "graph_replays" (forwards replayed from a
+ * captured hipGraph so far), "graphs_enabled". */
 int ttnet_plan_query(ttnet_plan *plan, const char *what, int64_t *out);
 
 /* Device time of the kernels of the last forward, measured with HIP events on the stream

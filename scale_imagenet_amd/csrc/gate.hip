@@ -166,8 +166,8 @@ __device__ inline uint32_t dw_row_4x4s2(const uint64_t (&rows)[4], const uint32_
 // dw: lane = (channel c = lane&15, row slot = lane>>4); each lane walks one output row of its
 // channel; the ballot of the wave is four channel words (4 rows x 16 channels) of one column.
 template <int KH, int KW, int STRIDE, int PAD, int H, int HO>
-__global__ __launch_bounds__(kGateThreads) void gate_stage1_kernel(GateBlockArgs a, int n_dw, int dw_blocks, int ips_dw,
-                                                                  int ips_pw) {
+__global__ __launch_bounds__(kGateThreads) void gate_stage1_kernel(GateBlockArgs a, int n_dw, int dw_blocks, int slices_dw,
+                                                                  int slices_pw) {
   extern __shared__ __align__(16) uint8_t lds[];
   constexpr int W = H, WO = HO;
   const int Q = a.C / 16;
@@ -176,9 +176,10 @@ __global__ __launch_bounds__(kGateThreads) void gate_stage1_kernel(GateBlockArgs
   if ((int)blockIdx.x < dw_blocks) {
     const int unit = blockIdx.x % n_dw;
     const int q = unit >> 1, branch = unit & 1;
-    const int n0 = (blockIdx.x / n_dw) * ips_dw;
+    const int sl = blockIdx.x / n_dw;                   // batch slices of (almost) equal size
+    const int n0 = (int)((long long)sl * a.n / slices_dw);
     if (n0 >= a.n) return;
-    const int n1 = min(a.n, n0 + ips_dw);
+    const int n1 = (int)((long long)(sl + 1) * a.n / slices_dw);
     const uint8_t *tab = (branch ? a.t_dw2 : a.t_dw1) + (size_t)q * kTableLds;
     uint16_t *out = branch ? a.o2 : a.o1;
     stage_lds_async(lds, tab, kTableLds);
@@ -235,9 +236,10 @@ __global__ __launch_bounds__(kGateThreads) void gate_stage1_kernel(GateBlockArgs
     // Block_conv3 (16 -> 16 bits per pixel and group) + majority pools of conv3(x) and of x
     const int b = blockIdx.x - dw_blocks;
     const int q = b % Q;
-    const int n0 = (b / Q) * ips_pw;
+    const int sl = b / Q;
+    const int n0 = (int)((long long)sl * a.n / slices_pw);
     if (n0 >= a.n) return;
-    const int n1 = min(a.n, n0 + ips_pw);
+    const int n1 = (int)((long long)(sl + 1) * a.n / slices_pw);
     stage_lds_async(lds, (const uint8_t *)(a.t_c3 + (size_t)q * 65536), kTableLds);
     wait_lds_stage();
     const uint16_t *tab = (const uint16_t *)lds;
@@ -293,15 +295,15 @@ struct BitBallots {
 // 16 channels comes from 16 ballots (a wave covers whole image rows).
 template <int HO>
 __global__ __launch_bounds__(kGateThreads) void gate_pf_kernel(GateBlockArgs a, const uint8_t *t_cf, uint16_t *out_cp,
-                                                              uint64_t *out_rp, int ips) {
+                                                              uint64_t *out_rp, int slices) {
   extern __shared__ __align__(16) uint8_t lds[];
   constexpr int WO = HO;
   constexpr int LPR = WO <= 16 ? 16 : 32, RPW = 64 / LPR, chunks = (HO + RPW - 1) / RPW;
   const int j = blockIdx.x;              // output word; groups 2j, 2j+1
   const int Q = a.C / 16, Qout = a.C / 8, Cout = 2 * a.C;
-  const int n0 = blockIdx.y * ips;
+  const int n0 = (int)((long long)blockIdx.y * a.n / slices);
   if (n0 >= a.n) return;
-  const int n1 = min(a.n, n0 + ips);
+  const int n1 = (int)((long long)(blockIdx.y + 1) * a.n / slices);
   stage_lds_async(lds, t_cf + (size_t)(2 * j) * 65536, kTableLds);
   const int wq = j >> 1, sh = 8 * (j & 1);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = kGateThreads / 64;
@@ -448,31 +450,25 @@ __global__ void rp_to_cp_kernel(const uint64_t *rp, uint16_t *cp, int n, int C, 
   }
 }
 
-// images per slice so that `units` table sets spread over about `target` workgroups
-int imgs_per_slice(int n, int units, int target) {
-  int slices = std::max(1, target / std::max(1, units));
-  slices = std::min(slices, n);
-  return (n + slices - 1) / slices;
-}
+// batch slices per table set so that `units` table sets spread over at most `target` workgroups
+int slices_for(int n, int units, int target) { return std::max(1, std::min(n, target / std::max(1, units))); }
 
 template <typename K>
 int allow_big_lds(K kernel, size_t bytes) {
-  if (bytes > 64 * 1024)
-    TT_HIP(hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
-  return TTNET_OK;
+  return ensure_dynamic_lds((const void *)kernel, bytes);
 }
 
 template <int H, int HO>
 int launch_stage1_t(const GateBlockArgs &a, hipStream_t s) {
-  // 1 workgroup per CU (128 KiB of tables in LDS).  The depthwise units carry ~95 % of the
-  // work: they get one round of the chip; the conv3 units are latency bound, so they are cut
-  // fine (more blocks in flight) and run in the shadow of the depthwise tail.
+  // 1 workgroup per CU (128 KiB of tables in LDS), and every workgroup pays ~2 us of table
+  // staging: the whole launch is one round of the chip, 224 depthwise + 32 conv3 workgroups
+  // (measured best split at B = 256; a second round of conv3 blocks cost 3-5 us per launch).
   const int n_dw = (a.C / 16) * 2, n_pw = a.C / 16;
-  const int ips_dw = imgs_per_slice(a.n, n_dw, 232), ips_pw = imgs_per_slice(a.n, n_pw, 192);
-  const int dw_blocks = n_dw * ((a.n + ips_dw - 1) / ips_dw), pw_blocks = n_pw * ((a.n + ips_pw - 1) / ips_pw);
+  const int sl_dw = slices_for(a.n, n_dw, 224), sl_pw = slices_for(a.n, n_pw, 32);
+  const int dw_blocks = n_dw * sl_dw, pw_blocks = n_pw * sl_pw;
   auto k = gate_stage1_kernel<4, 4, 2, 2, H, HO>;
   TT_TRY(allow_big_lds(k, kTableLds));
-  hipLaunchKernelGGL(k, dim3(dw_blocks + pw_blocks), dim3(kGateThreads), kTableLds, s, a, n_dw, dw_blocks, ips_dw, ips_pw);
+  hipLaunchKernelGGL(k, dim3(dw_blocks + pw_blocks), dim3(kGateThreads), kTableLds, s, a, n_dw, dw_blocks, sl_dw, sl_pw);
   TT_HIP(hipGetLastError());
   return TTNET_OK;
 }
@@ -480,10 +476,10 @@ int launch_stage1_t(const GateBlockArgs &a, hipStream_t s) {
 template <int HO>
 int launch_pf_t(const GateBlockArgs &a, const uint8_t *t_cf, uint16_t *out_cp, uint64_t *out_rp, hipStream_t s) {
   const int units = a.C / 8;
-  const int ips = imgs_per_slice(a.n, units, 256);
+  const int slices = slices_for(a.n, units, 256);
   auto k = gate_pf_kernel<HO>;
   TT_TRY(allow_big_lds(k, kTableLds));
-  hipLaunchKernelGGL(k, dim3(units, (a.n + ips - 1) / ips), dim3(kGateThreads), kTableLds, s, a, t_cf, out_cp, out_rp, ips);
+  hipLaunchKernelGGL(k, dim3(units, slices), dim3(kGateThreads), kTableLds, s, a, t_cf, out_cp, out_rp, slices);
   TT_HIP(hipGetLastError());
   return TTNET_OK;
 }

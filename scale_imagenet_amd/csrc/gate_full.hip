@@ -177,7 +177,7 @@ int launch_full_pw(const FullPwArgs &a, hipStream_t s) {
     return TTNET_E_UNSUPPORTED;
   }
   if (lds > 64 * 1024)
-    TT_HIP(hipFuncSetAttribute((const void *)full_pw_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    TT_TRY(ensure_dynamic_lds((const void *)full_pw_kernel, lds));
   const int rows = a.n * a.H;
   const int chunks = std::max(1, std::min((rows + 3) / 4, std::max(1, 512 / a.groups)));
   hipLaunchKernelGGL(full_pw_kernel, dim3(a.groups, chunks), dim3(256), lds, s, a);

@@ -292,7 +292,7 @@ int launch_gemm_f16x2(const void *Af, const void *Bf, float *part, int M, int N,
     set_error("gemm_f16x2: K=%d not divisible into %d slices of %d k-steps", K, splits, G_KS);
     return TTNET_E_UNSUPPORTED;
   }
-  TT_HIP(hipFuncSetAttribute((const void *)gemm_f16x2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, G_LDS));
+  TT_TRY(ensure_dynamic_lds((const void *)gemm_f16x2_kernel, G_LDS));
   const int n_tiles = (N + G_BN - 1) / G_BN, m_tiles = (M + G_BM - 1) / G_BM;
   hipLaunchKernelGGL(gemm_f16x2_kernel, dim3(n_tiles * m_tiles * splits), dim3(64 * G_WAVES), G_LDS, s, (const uint8_t *)Af,
                      (const uint8_t *)Bf, part, M, N, KS, KS / splits, n_tiles, m_tiles, splits);

@@ -126,7 +126,7 @@ int launch_lut_build(const LutBuildArgs &a, hipStream_t s) {
     return TTNET_E_UNSUPPORTED;
   }
   auto k = lut_build_kernel<16>;
-  if (lds > 64 * 1024) TT_HIP(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  TT_TRY(ensure_dynamic_lds((const void *)k, lds));
   hipLaunchKernelGGL(k, grid, dim3(kThreads), lds, s, a);
   TT_HIP(hipGetLastError());
   return TTNET_OK;

@@ -10,12 +10,17 @@
 #include <dlfcn.h>
 #include <math.h>
 #include <stdarg.h>
+#include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
 #include <map>
 #include <memory>
+
+#include <mutex>
+#include <unordered_map>
 
 #include "ttnet_common.h"
 
@@ -121,11 +126,40 @@ struct ttnet_plan {
   int64_t last_n = 0;
 
   bool profiling = false;
+  // captured forward per batch size (hipGraph): one launch instead of ~11 on the host side
+  struct GraphEntry {
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    hipGraphNode_t first = nullptr, last = nullptr;     // the kernels that read x / write the logits
+    // own copies of those two kernels' launch parameters (argument values in 8-byte slots)
+    hipKernelNodeParams first_p{}, last_p{};
+    uint64_t first_argv[8] = {}, last_argv[8] = {};
+    void *first_args[8] = {}, *last_args[8] = {};
+    const void *x = nullptr;
+    void *out = nullptr;
+  };
+  std::map<int64_t, GraphEntry> graphs;
+  std::map<int64_t, int> eager_calls;
+  hipStream_t cap_stream = nullptr;
+  bool graphs_ok = getenv("TTNET_NO_GRAPH") == nullptr;   // plain launches only when set (debugging)
+  int64_t graph_replays = 0;
   std::vector<Timing> timings;
   size_t timing_used = 0;
 
   std::vector<void *> owned;        // everything hipMalloc'ed, freed in destroy
 };
+
+int ttnet::ensure_dynamic_lds(const void *kernel, size_t bytes) {
+  if (bytes <= 64 * 1024) return TTNET_OK;
+  static std::mutex mu;
+  static std::unordered_map<const void *, size_t> done;
+  std::lock_guard<std::mutex> lock(mu);
+  auto it = done.find(kernel);
+  if (it != done.end() && it->second >= bytes) return TTNET_OK;
+  TT_HIP(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+  done[kernel] = bytes;
+  return TTNET_OK;
+}
 
 namespace {
 
@@ -837,9 +871,9 @@ int ttnet_plan_finalize(ttnet_plan *pl, void *stream) {
   return TTNET_OK;
 }
 
-int ttnet_forward(ttnet_plan *pl, const float *x_dev, int64_t n, float *logits_dev, void *stream) {
-  TT_TRY(check_ready(pl, x_dev, n, logits_dev));
-  hipStream_t s = (hipStream_t)stream;
+namespace {
+
+int forward_eager(ttnet_plan *pl, const float *x_dev, int64_t n, float *logits_dev, hipStream_t s) {
   pl->timing_used = 0;
   if (pl->va) {
     TT_TIMED(pl, "va.stem", s,
@@ -852,6 +886,139 @@ int ttnet_forward(ttnet_plan *pl, const float *x_dev, int64_t n, float *logits_d
            launch_stem(x_dev, pl->stem_wt, pl->stem_init, pl->x_rp[0], pl->full ? nullptr : pl->x_cp[0], (int)n,
                        pl->p, s));
   return run_from_blocks(pl, (int)n, logits_dev, s);
+}
+
+// The forward is a fixed chain of ~11 launches whose host cost (~20 us each) equals the device
+// time at batch 256, so from the third call with a given batch size on it is replayed as a
+// hipGraph captured on a private stream.  Only two pointers change between calls: the input
+// (argument 0 of the first kernel) and the logits (argument 4 of lin2, the last kernel); they
+// are patched into the instantiated graph when they differ from the previous call.
+constexpr int kFirstKernelArgs = 7, kLastKernelArgs = 8, kLastKernelOutArg = 4;
+
+void drop_graph(ttnet_plan::GraphEntry &e) {
+  if (e.exec) (void)hipGraphExecDestroy(e.exec);
+  if (e.graph) (void)hipGraphDestroy(e.graph);
+  e = ttnet_plan::GraphEntry{};
+}
+
+// Copy a kernel node's launch parameters into storage we own.  sizes[i] = byte size of argument i.
+// (The arrays returned by hipGraphKernelNodeGetParams belong to the node: they are read once,
+// here, and never handed back to the runtime.)
+bool own_params(hipGraphNode_t node, const int *sizes, int nargs, hipKernelNodeParams &p, uint64_t *argv, void **args) {
+  hipKernelNodeParams q{};
+  if (hipGraphKernelNodeGetParams(node, &q) != hipSuccess || !q.kernelParams || q.extra) return false;
+  for (int i = 0; i < nargs; ++i) {
+    if (!q.kernelParams[i]) return false;
+    argv[i] = 0;
+    memcpy(&argv[i], q.kernelParams[i], (size_t)sizes[i]);
+    args[i] = &argv[i];
+  }
+  p = q;
+  p.kernelParams = args;
+  p.extra = nullptr;
+  return true;
+}
+
+bool capture_forward(ttnet_plan *pl, const float *x_dev, int64_t n, float *logits_dev, ttnet_plan::GraphEntry &e) {
+  if (!pl->cap_stream && hipStreamCreateWithFlags(&pl->cap_stream, hipStreamNonBlocking) != hipSuccess) return false;
+  if (hipStreamBeginCapture(pl->cap_stream, hipStreamCaptureModeThreadLocal) != hipSuccess) return false;
+  const int r = forward_eager(pl, x_dev, n, logits_dev, pl->cap_stream);
+  hipGraph_t g = nullptr;
+  const hipError_t ee = hipStreamEndCapture(pl->cap_stream, &g);
+  if (r != TTNET_OK || ee != hipSuccess || !g) {
+    if (g) (void)hipGraphDestroy(g);
+    (void)hipGetLastError();
+    return false;
+  }
+  e.graph = g;
+  if (hipGraphInstantiate(&e.exec, g, nullptr, nullptr, 0) != hipSuccess) return false;
+  // a single chain: walk from the root to the leaf
+  hipGraphNode_t node = nullptr;
+  size_t cnt = 1;
+  if (hipGraphGetRootNodes(g, &node, &cnt) != hipSuccess || cnt != 1) return false;
+  e.first = node;
+  for (int guard = 0; guard < 1000; ++guard) {
+    size_t nd = 0;
+    if (hipGraphNodeGetDependentNodes(node, nullptr, &nd) != hipSuccess) return false;
+    if (nd == 0) break;
+    if (nd != 1) return false;
+    hipGraphNode_t next = nullptr;
+    if (hipGraphNodeGetDependentNodes(node, &next, &nd) != hipSuccess) return false;
+    node = next;
+  }
+  e.last = node;
+  hipGraphNodeType t0, t1;
+  if (hipGraphNodeGetType(e.first, &t0) != hipSuccess || hipGraphNodeGetType(e.last, &t1) != hipSuccess ||
+      t0 != hipGraphNodeTypeKernel || t1 != hipGraphNodeTypeKernel || e.first == e.last)
+    return false;
+  static const int first_sizes[7] = {8, 8, 8, 8, 8, 4, 4};        // stem_pc_kernel(x, wfrag, init, rp, cp, p, n)
+  static const int first_sizes_va[7] = {8, 8, 8, 8, 8, 8, 4};     // va_stem_kernel(x, w, bias, scale, shift, rp, n)
+  static const int last_sizes[8] = {8, 8, 8, 4, 8, 4, 4, 4};      // lin2_f16x2_kernel(A, B, bias, inv, out, M, N, KS)
+  if (!own_params(e.first, pl->va ? first_sizes_va : first_sizes, kFirstKernelArgs, e.first_p, e.first_argv, e.first_args) ||
+      !own_params(e.last, last_sizes, kLastKernelArgs, e.last_p, e.last_argv, e.last_args))
+    return false;
+  // the two slots that will be patched must hold exactly the pointers this capture ran with
+  if (e.first_argv[0] != (uint64_t)(uintptr_t)x_dev || e.last_argv[kLastKernelOutArg] != (uint64_t)(uintptr_t)logits_dev ||
+      e.last_argv[5] != (uint64_t)n)
+    return false;
+  e.x = x_dev;
+  e.out = logits_dev;
+  return true;
+}
+
+}  // namespace
+
+int ttnet_forward(ttnet_plan *pl, const float *x_dev, int64_t n, float *logits_dev, void *stream) {
+  TT_TRY(check_ready(pl, x_dev, n, logits_dev));
+  hipStream_t s = (hipStream_t)stream;
+  if (pl->profiling || !pl->graphs_ok) return forward_eager(pl, x_dev, n, logits_dev, s);
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  if (s && hipStreamIsCapturing(s, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone)
+    return forward_eager(pl, x_dev, n, logits_dev, s);       // the caller is capturing us into a graph of their own
+  auto it = pl->graphs.find(n);
+  if (it == pl->graphs.end()) {
+    if (++pl->eager_calls[n] <= 2) return forward_eager(pl, x_dev, n, logits_dev, s);   // warm: attributes, lazy module load
+    ttnet_plan::GraphEntry e;
+    if (!capture_forward(pl, x_dev, n, logits_dev, e)) {
+      drop_graph(e);
+      pl->graphs_ok = false;                                   // stay on plain launches
+      (void)hipGetLastError();
+      return forward_eager(pl, x_dev, n, logits_dev, s);
+    }
+    if (pl->graphs.size() >= 8) {                              // bound the cache: drop the oldest batch size
+      drop_graph(pl->graphs.begin()->second);
+      pl->graphs.erase(pl->graphs.begin());
+    }
+    it = pl->graphs.emplace(n, e).first;
+  }
+  ttnet_plan::GraphEntry &e = it->second;
+  bool ok = true;
+  if (e.x != x_dev) {
+    e.first_argv[0] = (uint64_t)(uintptr_t)x_dev;
+    e.first_p.kernelParams = e.first_args;          // (the entry may have been moved since capture)
+    for (int i = 0; i < kFirstKernelArgs; ++i) e.first_args[i] = &e.first_argv[i];
+    ok = hipGraphExecKernelNodeSetParams(e.exec, e.first, &e.first_p) == hipSuccess;
+    e.x = x_dev;
+  }
+  if (ok && e.out != logits_dev) {
+    e.last_argv[kLastKernelOutArg] = (uint64_t)(uintptr_t)logits_dev;
+    e.last_p.kernelParams = e.last_args;
+    for (int i = 0; i < kLastKernelArgs; ++i) e.last_args[i] = &e.last_argv[i];
+    ok = hipGraphExecKernelNodeSetParams(e.exec, e.last, &e.last_p) == hipSuccess;
+    e.out = logits_dev;
+  }
+  if (ok) ok = hipGraphLaunch(e.exec, s) == hipSuccess;
+  if (!ok) {
+    drop_graph(e);
+    pl->graphs.erase(it);
+    pl->graphs_ok = false;
+    (void)hipGetLastError();
+    return forward_eager(pl, x_dev, n, logits_dev, s);
+  }
+  pl->last_n = n;
+  pl->timing_used = 0;
+  pl->graph_replays++;
+  return TTNET_OK;
 }
 
 int ttnet_forward_from_stem_bits(ttnet_plan *pl, const uint64_t *rows_dev, int64_t n, float *logits_dev,
@@ -1041,6 +1208,8 @@ int ttnet_plan_query(ttnet_plan *pl, const char *what, int64_t *out) {
   else if (w == "table_bytes") *out = (int64_t)pl->table_bytes;
   else if (w == "workspace_bytes") *out = (int64_t)pl->workspace_bytes;
   else if (w == "p") *out = pl->p;
+  else if (w == "graph_replays") *out = pl->graph_replays;
+  else if (w == "graphs_enabled") *out = pl->graphs_ok ? 1 : 0;
   else if (w.rfind("near_ties:", 0) == 0) {
     BlockTT *b = find_block(pl, w.c_str() + 10);
     if (!b) {
@@ -1091,6 +1260,11 @@ void ttnet_plan_destroy(ttnet_plan *pl) {
     (void)hipEventDestroy(t.e0);
     (void)hipEventDestroy(t.e1);
   }
+  for (auto &kv : pl->graphs) {
+    if (kv.second.exec) (void)hipGraphExecDestroy(kv.second.exec);
+    if (kv.second.graph) (void)hipGraphDestroy(kv.second.graph);
+  }
+  if (pl->cap_stream) (void)hipStreamDestroy(pl->cap_stream);
   for (void *ptr : pl->owned) (void)hipFree(ptr);
   delete pl;
 }

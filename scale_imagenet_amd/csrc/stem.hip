@@ -369,7 +369,7 @@ int launch_stem(const float *x, const void *wfrag, const float *init, uint64_t *
     return TTNET_E_UNSUPPORTED;
   }
   const size_t lds = (size_t)2 * TILE * 2 + (size_t)2 * 64 * (NT + 2) * 4 + 64 * 4;
-  TT_HIP(hipFuncSetAttribute((const void *)stem_pc_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  TT_TRY(ensure_dynamic_lds((const void *)stem_pc_kernel, lds));
   const int items = n * (56 / SR);
   hipLaunchKernelGGL(stem_pc_kernel, dim3(std::min(items, 256)), dim3(STEM_THREADS), lds, s, x, (const uint4 *)wfrag, init, rp,
                      cp, p, n);

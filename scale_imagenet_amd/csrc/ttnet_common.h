@@ -78,6 +78,10 @@ __device__ inline void static_for(F &&f) {
 }
 #endif
 
+// Raise a kernel's dynamic LDS limit (> 64 KiB) once per kernel and process: the attribute call
+// costs host microseconds that a launch-bound forward cannot afford on every launch (plan.hip).
+int ensure_dynamic_lds(const void *kernel, size_t bytes);
+
 // ---- launchers (defined next to their kernels) ------------------------------------------
 
 // lut_build.hip

@@ -209,7 +209,26 @@ class _TTNetBase(nn.Module):
 
     # -- plan management ------------------------------------------------------------------
     def _state_signature(self):
-        return tuple((k, t.data_ptr(), t._version) for k, t in self.state_dict().items())
+        """(storage address, in-place version) of every state tensor.  ``state_dict()`` itself
+        costs ~0.5 ms of Python per call -- more than the whole forward at batch 256 -- so the
+        tensor list is cached; ``.to()`` / ``.cuda()`` / ``load_state_dict`` and in-place updates
+        are seen through the addresses and version counters, and the list itself is rebuilt by
+        ``_apply`` / ``load_state_dict`` / ``refresh_state()`` (call the latter after assigning a
+        new Parameter object to a sub-module by hand)."""
+        ts = self.__dict__.get("_sig_tensors")
+        if ts is None:
+            ts = list(self.state_dict().values())
+            self.__dict__["_sig_tensors"] = ts
+        return tuple((t.data_ptr(), t._version) for t in ts)
+
+    def refresh_state(self):
+        self.__dict__["_sig_tensors"] = None
+        return self
+
+    def _apply(self, fn, *a, **k):
+        out = super()._apply(fn, *a, **k)
+        self.__dict__["_sig_tensors"] = None
+        return out
 
     def _plan_for(self, device: torch.device, n: int) -> _Plan:
         idx = device.index if device.index is not None else torch.cuda.current_device()
@@ -334,7 +353,9 @@ class _TTNetBase(nn.Module):
     def load_state_dict(self, state_dict, strict: bool = True, **kw):
         if state_dict and all(k.startswith("module.") for k in state_dict):
             state_dict = OrderedDict((k[len("module."):], v) for k, v in state_dict.items())
-        return super().load_state_dict(state_dict, strict=strict, **kw)
+        out = super().load_state_dict(state_dict, strict=strict, **kw)
+        self.__dict__["_sig_tensors"] = None
+        return out
 
 
 class TT_vf_19lv3_imgnet_small(_TTNetBase):

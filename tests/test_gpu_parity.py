@@ -259,6 +259,31 @@ def test_full_batch_properties(small_model, dev):
     assert len(set(y1.argmax(1).tolist())) > 20          # the synthetic classifier is not degenerate
 
 
+def test_graph_replay_matches_plain_launches(small_model, dev):
+    """From the third forward with one batch size the C ABI replays a captured hipGraph; the
+    replay must equal the plain launches bit for bit, with fresh input / output buffers."""
+    model = small_model
+    n = 24
+    xs = [torch.from_numpy(synth.synth_images(n, first=100 * i)).to(dev) for i in range(3)]
+    model.set_profiling(True)                       # profiling mode = plain launches
+    with torch.no_grad():
+        want = [model(x).clone() for x in xs]
+    model.set_profiling(False)
+    plan = model._any_plan()
+    before = plan.query("graph_replays")
+    with torch.no_grad():
+        for _ in range(3):
+            model(xs[0])                            # warm-up calls and the capture
+        got = [model(x).clone() for x in xs]        # replays with patched pointers
+        rows = model.read_stage("features.3", n).copy()
+    torch.cuda.synchronize()
+    if plan.query("graphs_enabled"):
+        assert plan.query("graph_replays") > before
+    for g, w in zip(got, want):
+        assert torch.equal(g, w)
+    assert rows.shape[0] == n
+
+
 def test_majority_and_padding_edges(model, variant, dev):
     """Edge inputs of the integer path: all-zero and all-one stem bits, checked against the
     bit oracle with the GPU's own tables."""
