@@ -129,9 +129,12 @@ def cpu_baseline(spec, st, budget_s: float = 15.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=256, help="images per GPU per step")
+    ap.add_argument("--inflight", type=int, default=2,
+                    help="batches kept in flight (model lanes on separate HIP streams, as evaluate.py runs the "
+                         "eval loop); 1 = one batch at a time. The serial figure is reported alongside.")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--variant", default="small", choices=["small", "xsmall", "full", "valexnet"],
                     help="small = BASELINE.json configs[1] (the headline); the others are parity-test configs")
@@ -161,39 +164,57 @@ def main():
     n_total = B * world
     x = torch.from_numpy(synth.synth_images(B, first=rank * B, hw=spec.image_hw)).to(dev)      # resident in HBM
 
-    def step():
+    R = max(1, args.inflight)
+    if R > 1:
+        model.set_lanes(R)
+    streams = [torch.cuda.Stream(dev) for _ in range(R)]
+
+    def step(i=0, lanes=1):
+        """One step = one forward of one batch (+ the logits all-gather when world > 1).  With
+        lanes > 1, step i runs on lane i % lanes and its own stream, so consecutive steps overlap."""
         with torch.no_grad():
-            y = model(x)
-            return all_gather_logits(y, n_total) if world > 1 else y
+            if lanes == 1:
+                y = model(x)
+                return all_gather_logits(y, n_total) if world > 1 else y
+            lane = i % lanes
+            with torch.cuda.stream(streams[lane]):
+                y = model(x, lane=lane)
+                return all_gather_logits(y, n_total) if world > 1 else y
 
     def fence():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    for _ in range(args.warmup):
-        step()
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        y = step()
-    fence()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        gloo = dist.get_backend() == "gloo"
-        t = torch.tensor([elapsed], device="cpu" if gloo else dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    def timed(lanes):
+        for i in range(max(args.warmup, 3 * lanes)):     # (3 calls per lane: two plain, then the graph capture)
+            step(i, lanes)
+        fence()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            step(i, lanes)
+        fence()
+        el = time.perf_counter() - t0
+        if world > 1:
+            gloo = dist.get_backend() == "gloo"
+            t = torch.tensor([el], device="cpu" if gloo else dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        return el
+
+    elapsed_serial = timed(1)
+    elapsed = timed(R) if R > 1 else elapsed_serial
 
     # second pass: per-kernel device time with HIP events on the launch stream
     model.set_profiling(True)
     acc = {}
-    for _ in range(args.steps):
+    prof_steps = min(args.steps, 30)
+    for _ in range(prof_steps):
         step()
         for k, v in model.last_timings().items():
             acc[k] = acc.get(k, 0.0) + v
     model.set_profiling(False)
-    avg_ms = {k: v / args.steps for k, v in acc.items()}
+    avg_ms = {k: v / prof_steps for k, v in acc.items()}
 
     if rank == 0:
         models = kernel_models(B) if args.variant == "small" else {}
@@ -242,8 +263,12 @@ def main():
             "config": {"workload": (f"TT_general_imagenet_v2_small forward, batch={B} 224x224 per GPU, "
                                     f"bit-packed HIP LUT kernels (BASELINE.json configs[1])") if args.variant == "small"
                        else f"TT {args.variant} variant forward, batch={B} 224x224 per GPU (parity-test configuration)",
-                       "batch_per_gpu": B, "global_batch": n_total,
+                       "batch_per_gpu": B, "global_batch": n_total, "batches_in_flight": R,
                        "parallelism": f"batch shard x{world}" + (" + RCCL all-gather of logits" if world > 1 else "")},
+            "inflight": R,
+            "serial": {"value": round(n_total * args.steps / elapsed_serial, 2),
+                       "ms_per_step": round(1e3 * elapsed_serial / args.steps, 4),
+                       "note": "the same K steps with one batch in flight (every step waits for the previous one)"},
             "roofline": roofline,
             "roofline_kernels": kernels + [gate],
             "traffic_source": traffic_src,

@@ -100,6 +100,17 @@ int ttnet_plan_finalize(ttnet_plan *plan, void *stream);
  * TTNET_NO_GRAPH=1 in the environment keeps plain launches.  Results are identical either way. */
 int ttnet_forward(ttnet_plan *plan, const float *x_dev, int64_t n, float *logits_dev, void *stream);
 
+/* Batches in flight.  A plan starts with one lane = one set of activation buffers; lanes share
+ * the weights and truth tables.  ttnet_plan_set_lanes grows the plan to `lanes` sets (1..16),
+ * and ttnet_forward_lane runs a forward on one of them: forwards on different lanes may be in
+ * flight together on different streams (the ramp and tail of one batch's kernels are filled by
+ * another's; this is how the eval loop of main.py:255-275 is pipelined, evaluate.py).  Calls on
+ * one plan are still issued from one thread at a time; a lane must not be reused before the
+ * forward issued on it has finished or been ordered before the new one by its stream.
+ * ttnet_forward is lane 0; ttnet_read_stage reads the lane used last. */
+int ttnet_plan_set_lanes(ttnet_plan *plan, int lanes);
+int ttnet_forward_lane(ttnet_plan *plan, int lane, const float *x_dev, int64_t n, float *logits_dev, void *stream);
+
 /* Same, starting from the binarised stem output (features[3], netbin.py:193) given as
  * row-packed bits uint64 [n][p][56]; used by the parity tests to separate the integer
  * gate path (bit exact) from the float stem (exact except at near ties). */
@@ -127,7 +138,7 @@ int ttnet_plan_set_table(ttnet_plan *plan, const char *name, const void *src_hos
 /* Integer facts about the plan: "fcsize", "n_classes", "n_state_tensors", "max_batch",
  * "near_ties:<block_tt name>" (entries with |pre-activation| < 1e-5 found while building
  * that table), "table_bytes", "workspace_bytes", "graph_replays" (forwards replayed from a
- * captured hipGraph so far), "graphs_enabled". */
+ * captured hipGraph so far), "graphs_enabled", "lanes". */
 int ttnet_plan_query(ttnet_plan *plan, const char *what, int64_t *out);
 
 /* Device time of the kernels of the last forward, measured with HIP events on the stream

@@ -16,6 +16,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <array>
 #include <map>
 #include <memory>
 
@@ -138,8 +139,24 @@ struct ttnet_plan {
     const void *x = nullptr;
     void *out = nullptr;
   };
-  std::map<int64_t, GraphEntry> graphs;
-  std::map<int64_t, int> eager_calls;
+  // A lane = one set of activation buffers (+ the graphs captured over them).  Lanes share the
+  // weights and truth tables; forwards on different lanes may be in flight at the same time on
+  // different streams (ttnet_forward_lane).  The workspace pointers above always mirror the
+  // lane `cur`.
+  struct Lane {
+    std::vector<uint64_t *> x_rp;
+    std::vector<uint16_t *> x_cp;
+    std::vector<std::array<uint16_t *, 4>> o;
+    std::vector<uint64_t *> c3_tmp;
+    uint64_t *va_y = nullptr;
+    float *last_float = nullptr, *part = nullptr;
+    uint16_t *feat = nullptr, *mid_frag = nullptr;
+    std::map<int64_t, GraphEntry> graphs;
+    std::map<int64_t, int> eager_calls;
+    int64_t last_n = 0;
+  };
+  std::vector<Lane> lanes;
+  int cur = 0;
   hipStream_t cap_stream = nullptr;
   bool graphs_ok = getenv("TTNET_NO_GRAPH") == nullptr;   // plain launches only when set (debugging)
   int64_t graph_replays = 0;
@@ -387,64 +404,97 @@ int build_geometry(ttnet_plan *pl) {
   return TTNET_OK;
 }
 
-// lin2 operands: A = head_mid's output (rows padded to 64, zeroed once so that the k padding is 0),
-// B = the split weights (rows padded to 64)
-int alloc_lin2(ttnet_plan *pl, int nb, size_t *ws) {
+// Activation workspace of one lane, into the plan's current workspace pointers.  Everything is
+// zeroed once: the branch-padding borders, the k padding of lin2's A operand and the rows of the
+// lin1 operand beyond the batch are never written again.
+int alloc_workspace(ttnet_plan *pl) {
+  const int nb = pl->desc.max_batch;
+  size_t *ws = &pl->workspace_bytes;
   const int kpad = (pl->inter + 15) / 16 * 16;
+  if (pl->va) {
+    pl->x_rp.assign(1, nullptr);
+    pl->x_cp.assign(1, nullptr);
+    TT_TRY(dev_alloc(pl, &pl->x_rp[0], (size_t)nb * 64 * 10, true, ws));
+    TT_TRY(dev_alloc(pl, &pl->va_y, (size_t)nb * 256 * 11, true, ws));
+  } else {
+    pl->x_rp.assign(pl->blocks.size(), nullptr);
+    pl->x_cp.assign(pl->blocks.size(), nullptr);
+    for (size_t i = 0; i < pl->blocks.size(); ++i) {
+      MultiHead &mh = pl->blocks[i];
+      TT_TRY(dev_alloc(pl, &pl->x_rp[i], (size_t)nb * mh.C * mh.H, true, ws));
+      TT_TRY(dev_alloc(pl, &pl->x_cp[i], pl->full ? 8 : (size_t)nb * mh.H * mh.W * (mh.C / 16), true, ws));
+      if (pl->full) TT_TRY(dev_alloc(pl, &mh.c3_tmp, (size_t)nb * mh.C * mh.H, true, ws));
+      for (int b = 0; b < 4; ++b) {
+        const size_t words16 = (size_t)nb * mh.Ho * mh.Wo * (mh.C / 16), rows64 = (size_t)nb * mh.C * mh.Ho;
+        TT_TRY(dev_alloc(pl, &mh.o[b], (pl->xs || pl->full) ? rows64 * 4 : words16, true, ws));
+      }
+    }
+    if (pl->full) {
+      const MultiHead &lb = pl->blocks.back();
+      TT_TRY(dev_alloc(pl, &pl->last_float, (size_t)nb * lb.cf.g.out_planes * lb.Ho * lb.Wo, true, ws));
+    }
+  }
+  const int nb_pad = (nb + 255) / 256 * 256;          // the lin1 GEMM walks whole 256-row tiles
+  TT_TRY(dev_alloc(pl, &pl->feat, frag_elems(nb_pad, pl->fcsize), true, ws));
   TT_TRY(dev_alloc(pl, &pl->mid_frag, frag_elems((nb + 63) / 64 * 64, kpad), true, ws));
-  TT_TRY(dev_alloc(pl, &pl->w2f, frag_elems((pl->n_classes + 63) / 64 * 64, kpad), true));
+  size_t pe = 0;
+  for (int n = 1; n <= nb; ++n) pe = std::max(pe, (size_t)gemm_f16x2_splits(n, pl->inter, pl->fcsize / 16) * n * pl->inter);
+  pl->part_elems = pe;
+  TT_TRY(dev_alloc(pl, &pl->part, pe, false, ws));
   return TTNET_OK;
 }
 
+void store_lane(ttnet_plan *pl, ttnet_plan::Lane &l) {
+  l.x_rp = pl->x_rp;
+  l.x_cp = pl->x_cp;
+  l.o.resize(pl->blocks.size());
+  l.c3_tmp.resize(pl->blocks.size());
+  for (size_t i = 0; i < pl->blocks.size(); ++i) {
+    for (int b = 0; b < 4; ++b) l.o[i][b] = pl->blocks[i].o[b];
+    l.c3_tmp[i] = pl->blocks[i].c3_tmp;
+  }
+  l.va_y = pl->va_y;
+  l.last_float = pl->last_float;
+  l.part = pl->part;
+  l.feat = pl->feat;
+  l.mid_frag = pl->mid_frag;
+}
+
+void load_lane(ttnet_plan *pl, const ttnet_plan::Lane &l) {
+  pl->x_rp = l.x_rp;
+  pl->x_cp = l.x_cp;
+  for (size_t i = 0; i < pl->blocks.size(); ++i) {
+    for (int b = 0; b < 4; ++b) pl->blocks[i].o[b] = l.o[i][b];
+    pl->blocks[i].c3_tmp = l.c3_tmp[i];
+  }
+  pl->va_y = l.va_y;
+  pl->last_float = l.last_float;
+  pl->part = l.part;
+  pl->feat = l.feat;
+  pl->mid_frag = l.mid_frag;
+}
+
+void switch_lane(ttnet_plan *pl, int k) {
+  if (k == pl->cur) return;
+  load_lane(pl, pl->lanes[k]);
+  pl->cur = k;
+}
+
 int allocate(ttnet_plan *pl) {
-  const int nb = pl->desc.max_batch;
-  size_t *ws = &pl->workspace_bytes, *tb = &pl->table_bytes;
+  size_t *tb = &pl->table_bytes;
+  const int kpad = (pl->inter + 15) / 16 * 16;
   for (auto &kv : pl->tensors) TT_TRY(dev_alloc(pl, (uint8_t **)&kv.second.dev, kv.second.bytes, true));
   if (pl->va) {
-    MultiHead &mh = pl->blocks[0];
-    pl->x_rp.resize(1);
-    pl->x_cp.resize(1);
-    TT_TRY(dev_alloc(pl, &pl->x_rp[0], (size_t)nb * 64 * 10, true, ws));
-    TT_TRY(dev_alloc(pl, &pl->va_y, (size_t)nb * 256 * 11, true, ws));
     TT_TRY(dev_alloc(pl, &pl->va_scale, 64, false));
     TT_TRY(dev_alloc(pl, &pl->va_shift, 64, false));
-    for (BlockTT *b : {&mh.c1, &mh.c2, &mh.c3}) {
-      const BlockGeom &g = b->g;
-      TT_TRY(dev_alloc(pl, (uint8_t **)&b->table, g.table_bytes(), true, tb));
-      TT_TRY(dev_alloc(pl, &b->perm_dev, b->perm.size(), false));
-      TT_HIP(hipMemcpy(b->perm_dev, b->perm.data(), b->perm.size(), hipMemcpyHostToDevice));
-      TT_TRY(dev_alloc(pl, &b->s1, (size_t)8 * g.in_planes, false));
-      TT_TRY(dev_alloc(pl, &b->t1, (size_t)8 * g.in_planes, false));
-      TT_TRY(dev_alloc(pl, &b->s2, g.out_planes, false));
-      TT_TRY(dev_alloc(pl, &b->t2, g.out_planes, false));
-      TT_TRY(dev_alloc(pl, &b->near_dev, 1, true));
-    }
-    const int nb_pad_va = (nb + 255) / 256 * 256;
-    TT_TRY(dev_alloc(pl, &pl->feat, frag_elems(nb_pad_va, pl->fcsize), true, ws));
-    TT_TRY(dev_alloc(pl, &pl->w1f, frag_elems(128, pl->fcsize), false));
-    TT_TRY(dev_alloc(pl, &pl->bn_scale, pl->inter, false));
-    TT_TRY(dev_alloc(pl, &pl->bn_shift, pl->inter, false));
-    TT_TRY(alloc_lin2(pl, nb, ws));
-    size_t pe_va = 0;
-    for (int n = 1; n <= nb; ++n) pe_va = std::max(pe_va, (size_t)gemm_f16x2_splits(n, pl->inter, pl->fcsize / 16) * n * pl->inter);
-    pl->part_elems = pe_va;
-    TT_TRY(dev_alloc(pl, &pl->part, pe_va, false, ws));
-    return TTNET_OK;
+  } else {
+    TT_TRY(dev_alloc(pl, &pl->stem_wt, stem_split_weights_elems(), false));
+    TT_TRY(dev_alloc(pl, &pl->stem_init, 64, false));
+    TT_TRY(dev_alloc(pl, &pl->w1p, (size_t)pl->inter * pl->fcsize, false));
   }
-  TT_TRY(dev_alloc(pl, &pl->stem_wt, stem_split_weights_elems(), false));
-  TT_TRY(dev_alloc(pl, &pl->stem_init, 64, false));
-  pl->x_rp.resize(pl->blocks.size());
-  pl->x_cp.resize(pl->blocks.size());
-  for (size_t i = 0; i < pl->blocks.size(); ++i) {
-    MultiHead &mh = pl->blocks[i];
-    TT_TRY(dev_alloc(pl, &pl->x_rp[i], (size_t)nb * mh.C * mh.H, true, ws));
-    TT_TRY(dev_alloc(pl, &pl->x_cp[i], pl->full ? 8 : (size_t)nb * mh.H * mh.W * (mh.C / 16), true, ws));
-    if (pl->full) TT_TRY(dev_alloc(pl, &mh.c3_tmp, (size_t)nb * mh.C * mh.H, true, ws));
-    for (int b = 0; b < 4; ++b) {  // zeroed once: the branch-padding border is never written again
-      const size_t words16 = (size_t)nb * mh.Ho * mh.Wo * (mh.C / 16), rows64 = (size_t)nb * mh.C * mh.Ho;
-      TT_TRY(dev_alloc(pl, &mh.o[b], (pl->xs || pl->full) ? rows64 * 4 : words16, true, ws));
-    }
+  for (auto &mh : pl->blocks) {
     for (BlockTT *b : {&mh.c1, &mh.c2, &mh.c3, &mh.cf}) {
+      if (pl->va && b == &mh.cf) continue;            // vAlexnet has no Block_convf
       const BlockGeom &g = b->g;
       if (!pl->full) {
         TT_TRY(dev_alloc(pl, (uint8_t **)&b->table, g.table_bytes(), true, tb));
@@ -458,21 +508,15 @@ int allocate(ttnet_plan *pl) {
       TT_TRY(dev_alloc(pl, &b->near_dev, 1, true));
     }
   }
-  const int nb_pad = (nb + 255) / 256 * 256;          // the lin1 GEMM walks whole 256-row tiles
-  TT_TRY(dev_alloc(pl, &pl->feat, frag_elems(nb_pad, pl->fcsize), true, ws));
-  if (pl->full) {
-    const MultiHead &lb = pl->blocks.back();
-    TT_TRY(dev_alloc(pl, &pl->last_float, (size_t)nb * lb.cf.g.out_planes * lb.Ho * lb.Wo, true, ws));
-  }
-  TT_TRY(dev_alloc(pl, &pl->w1p, (size_t)pl->inter * pl->fcsize, false));
-  TT_TRY(dev_alloc(pl, &pl->w1f, frag_elems((pl->inter + 127) / 128 * 128, pl->fcsize), false));
+  TT_TRY(dev_alloc(pl, &pl->w1f, frag_elems(pl->va ? 128 : (pl->inter + 127) / 128 * 128, pl->fcsize), false));
   TT_TRY(dev_alloc(pl, &pl->bn_scale, pl->inter, false));
   TT_TRY(dev_alloc(pl, &pl->bn_shift, pl->inter, false));
-  TT_TRY(alloc_lin2(pl, nb, ws));
-  size_t pe = 0;
-  for (int n = 1; n <= nb; ++n) pe = std::max(pe, (size_t)gemm_f16x2_splits(n, pl->inter, pl->fcsize / 16) * n * pl->inter);
-  pl->part_elems = pe;
-  TT_TRY(dev_alloc(pl, &pl->part, pe, false, ws));
+  TT_TRY(dev_alloc(pl, &pl->w2f, frag_elems((pl->n_classes + 63) / 64 * 64, kpad), true));
+  // lane 0
+  TT_TRY(alloc_workspace(pl));
+  pl->lanes.resize(1);
+  store_lane(pl, pl->lanes[0]);
+  pl->cur = 0;
   return TTNET_OK;
 }
 
@@ -968,16 +1012,44 @@ bool capture_forward(ttnet_plan *pl, const float *x_dev, int64_t n, float *logit
 
 }  // namespace
 
-int ttnet_forward(ttnet_plan *pl, const float *x_dev, int64_t n, float *logits_dev, void *stream) {
+int ttnet_plan_set_lanes(ttnet_plan *pl, int lanes) {
+  if (!pl || lanes < 1 || lanes > 16) {
+    set_error("set_lanes: %d outside [1,16]", lanes);
+    return TTNET_E_INVALID;
+  }
+  (void)hipSetDevice(pl->device);
+  const int keep = pl->cur;
+  while ((int)pl->lanes.size() < lanes) {
+    // allocate a fresh workspace into the plan's pointers, file it as a new lane, restore
+    pl->lanes[pl->cur].last_n = pl->last_n;
+    TT_TRY(alloc_workspace(pl));
+    pl->lanes.emplace_back();
+    store_lane(pl, pl->lanes.back());
+    load_lane(pl, pl->lanes[keep]);
+  }
+  return TTNET_OK;
+}
+
+int ttnet_forward_lane(ttnet_plan *pl, int lane, const float *x_dev, int64_t n, float *logits_dev, void *stream) {
   TT_TRY(check_ready(pl, x_dev, n, logits_dev));
+  if (lane < 0 || lane >= (int)pl->lanes.size()) {
+    set_error("forward: lane %d but the plan has %d (ttnet_plan_set_lanes)", lane, (int)pl->lanes.size());
+    return TTNET_E_INVALID;
+  }
+  if (lane != pl->cur) {
+    pl->lanes[pl->cur].last_n = pl->last_n;
+    switch_lane(pl, lane);
+    pl->last_n = pl->lanes[lane].last_n;
+  }
+  ttnet_plan::Lane &L = pl->lanes[lane];
   hipStream_t s = (hipStream_t)stream;
   if (pl->profiling || !pl->graphs_ok) return forward_eager(pl, x_dev, n, logits_dev, s);
   hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
   if (s && hipStreamIsCapturing(s, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone)
     return forward_eager(pl, x_dev, n, logits_dev, s);       // the caller is capturing us into a graph of their own
-  auto it = pl->graphs.find(n);
-  if (it == pl->graphs.end()) {
-    if (++pl->eager_calls[n] <= 2) return forward_eager(pl, x_dev, n, logits_dev, s);   // warm: attributes, lazy module load
+  auto it = L.graphs.find(n);
+  if (it == L.graphs.end()) {
+    if (++L.eager_calls[n] <= 2) return forward_eager(pl, x_dev, n, logits_dev, s);   // warm: attributes, lazy module load
     ttnet_plan::GraphEntry e;
     if (!capture_forward(pl, x_dev, n, logits_dev, e)) {
       drop_graph(e);
@@ -985,11 +1057,11 @@ int ttnet_forward(ttnet_plan *pl, const float *x_dev, int64_t n, float *logits_d
       (void)hipGetLastError();
       return forward_eager(pl, x_dev, n, logits_dev, s);
     }
-    if (pl->graphs.size() >= 8) {                              // bound the cache: drop the oldest batch size
-      drop_graph(pl->graphs.begin()->second);
-      pl->graphs.erase(pl->graphs.begin());
+    if (L.graphs.size() >= 8) {                                // bound the cache: drop the smallest batch size
+      drop_graph(L.graphs.begin()->second);
+      L.graphs.erase(L.graphs.begin());
     }
-    it = pl->graphs.emplace(n, e).first;
+    it = L.graphs.emplace(n, e).first;
   }
   ttnet_plan::GraphEntry &e = it->second;
   bool ok = true;
@@ -1010,7 +1082,7 @@ int ttnet_forward(ttnet_plan *pl, const float *x_dev, int64_t n, float *logits_d
   if (ok) ok = hipGraphLaunch(e.exec, s) == hipSuccess;
   if (!ok) {
     drop_graph(e);
-    pl->graphs.erase(it);
+    L.graphs.erase(it);
     pl->graphs_ok = false;
     (void)hipGetLastError();
     return forward_eager(pl, x_dev, n, logits_dev, s);
@@ -1019,6 +1091,10 @@ int ttnet_forward(ttnet_plan *pl, const float *x_dev, int64_t n, float *logits_d
   pl->timing_used = 0;
   pl->graph_replays++;
   return TTNET_OK;
+}
+
+int ttnet_forward(ttnet_plan *pl, const float *x_dev, int64_t n, float *logits_dev, void *stream) {
+  return ttnet_forward_lane(pl, 0, x_dev, n, logits_dev, stream);
 }
 
 int ttnet_forward_from_stem_bits(ttnet_plan *pl, const uint64_t *rows_dev, int64_t n, float *logits_dev,
@@ -1210,6 +1286,7 @@ int ttnet_plan_query(ttnet_plan *pl, const char *what, int64_t *out) {
   else if (w == "p") *out = pl->p;
   else if (w == "graph_replays") *out = pl->graph_replays;
   else if (w == "graphs_enabled") *out = pl->graphs_ok ? 1 : 0;
+  else if (w == "lanes") *out = (int64_t)pl->lanes.size();
   else if (w.rfind("near_ties:", 0) == 0) {
     BlockTT *b = find_block(pl, w.c_str() + 10);
     if (!b) {
@@ -1260,10 +1337,11 @@ void ttnet_plan_destroy(ttnet_plan *pl) {
     (void)hipEventDestroy(t.e0);
     (void)hipEventDestroy(t.e1);
   }
-  for (auto &kv : pl->graphs) {
-    if (kv.second.exec) (void)hipGraphExecDestroy(kv.second.exec);
-    if (kv.second.graph) (void)hipGraphDestroy(kv.second.graph);
-  }
+  for (auto &l : pl->lanes)
+    for (auto &kv : l.graphs) {
+      if (kv.second.exec) (void)hipGraphExecDestroy(kv.second.exec);
+      if (kv.second.graph) (void)hipGraphDestroy(kv.second.graph);
+    }
   if (pl->cap_stream) (void)hipStreamDestroy(pl->cap_stream);
   for (void *ptr : pl->owned) (void)hipFree(ptr);
   delete pl;

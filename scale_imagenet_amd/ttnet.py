@@ -133,6 +133,9 @@ class _Plan:
                                                       t.dim(), _DT[t.dtype], on_dev))
         _lib.check(self.lib.ttnet_plan_finalize(self.handle, C.c_void_p(stream)))
 
+    def set_lanes(self, lanes: int):
+        _lib.check(self.lib.ttnet_plan_set_lanes(self.handle, int(lanes)))
+
     def query(self, what: str) -> int:
         out = C.c_int64()
         _lib.check(self.lib.ttnet_plan_query(self.handle, what.encode(), C.byref(out)))
@@ -238,6 +241,8 @@ class _TTNetBase(nn.Module):
             plan = None
         if plan is None:
             plan = _Plan(self.spec, self.args, idx, max(n, self.DEFAULT_MAX_BATCH))
+            if self.__dict__.get("_lanes", 1) > 1:
+                plan.set_lanes(self._lanes)
             self._plans[idx] = plan
         sig = self._state_signature()
         if plan.signature != sig:
@@ -245,14 +250,23 @@ class _TTNetBase(nn.Module):
             plan.signature = sig
         return plan
 
+    def set_lanes(self, lanes: int):
+        """Activation workspaces for ``lanes`` batches in flight (``model(x, lane=k)``, each on
+        its own stream; see ttnet_forward_lane).  Weights and truth tables are shared."""
+        self.__dict__["_lanes"] = int(lanes)
+        for plan in self._plans.values():
+            plan.set_lanes(int(lanes))
+        return self
+
     def reserve(self, max_batch: int):
         """Size the activation workspace up front (otherwise it grows on demand)."""
         self.DEFAULT_MAX_BATCH = int(max_batch)
         return self
 
     # -- the hot path ------------------------------------------------------------------------
-    def forward(self, x: torch.Tensor) -> torch.Tensor:
-        """``self.features(x)`` of the reference (netbin.py:703-708), eval mode."""
+    def forward(self, x: torch.Tensor, lane: int = 0) -> torch.Tensor:
+        """``self.features(x)`` of the reference (netbin.py:703-708), eval mode.  ``lane`` picks
+        the activation workspace (``set_lanes``) when several batches are kept in flight."""
         if self.training:
             raise RuntimeError("the HIP path implements eval-mode inference only: call model.eval() "
                                "(main.py:251); training is out of scope")
@@ -269,8 +283,8 @@ class _TTNetBase(nn.Module):
         plan = self._plan_for(x.device, n)
         out = torch.empty((n, self.spec.n_classes), device=x.device, dtype=torch.float32)
         stream = torch.cuda.current_stream(x.device).cuda_stream
-        _lib.check(plan.lib.ttnet_forward(plan.handle, C.c_void_p(x.data_ptr()), n, C.c_void_p(out.data_ptr()),
-                                          C.c_void_p(stream)))
+        _lib.check(plan.lib.ttnet_forward_lane(plan.handle, int(lane), C.c_void_p(x.data_ptr()), n,
+                                               C.c_void_p(out.data_ptr()), C.c_void_p(stream)))
         return out
 
     # -- parity taps (replace Block_TT.input_layer / output_layer, TT_FHE_SMALL.py:310,319) --

@@ -284,6 +284,38 @@ def test_graph_replay_matches_plain_launches(small_model, dev):
     assert rows.shape[0] == n
 
 
+def test_lanes_in_flight_match_lane0(dev):
+    """Three batches in flight on three lanes / streams (shared tables, separate activation
+    workspaces) give the logits of the same batches run one at a time; evaluate() pipelined
+    equals evaluate() serial."""
+    from scale_imagenet_amd.evaluate import evaluate
+    spec, st = spec_and_state("small")
+    m = ttnet.TT_vf_19lv3_imgnet_small(args_for("small"))
+    m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in st.items()})
+    m = m.to(dev).eval().reserve(16)
+    xs = [torch.from_numpy(synth.synth_images(16, first=16 * i)).to(dev) for i in range(6)]
+    with torch.no_grad():
+        want = [m(x).clone() for x in xs]
+    m.set_lanes(3)
+    assert m._any_plan().query("lanes") == 3
+    streams = [torch.cuda.Stream(dev) for _ in range(3)]
+    got = [None] * len(xs)
+    with torch.no_grad():
+        for rep in range(4):                        # plain launches first, then captured graphs per lane
+            for i, x in enumerate(xs):
+                with torch.cuda.stream(streams[i % 3]):
+                    got[i] = m(x, lane=i % 3)
+    torch.cuda.synchronize()
+    for g, w in zip(got, want):
+        assert torch.equal(g, w)
+    with pytest.raises(Exception):
+        m(xs[0], lane=5)
+    batches = [(x.cpu(), torch.from_numpy(synth.synth_targets(16, first=16 * i))) for i, x in enumerate(xs)]
+    a = evaluate(m, batches, dev, inflight=1)
+    b = evaluate(m, batches, dev, inflight=3)
+    assert (a.loss, a.top1, a.top5, a.images) == (b.loss, b.top1, b.top5, b.images)
+
+
 def test_majority_and_padding_edges(model, variant, dev):
     """Edge inputs of the integer path: all-zero and all-one stem bits, checked against the
     bit oracle with the GPU's own tables."""
