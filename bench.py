@@ -54,7 +54,7 @@ def kernel_models(batch: int):
     m = {
         "stem": ("mfma_f16x2", 2.0 * STEM_MAC * batch),
         "head.lin1": ("mfma_f16x2", 2.0 * LIN1_MAC * batch),
-        "head.lin2": ("mfma", 2.0 * LIN2_MAC * batch),
+        "head.lin2": ("mfma_f16x2", 2.0 * LIN2_MAC * batch),
         "head.bn_poly": ("hbm", 8.0 * 1000 * batch),
         "head.bias": ("hbm", 8.0 * 1000 * batch),
     }
