@@ -135,6 +135,9 @@ def main():
     ap.add_argument("--inflight", type=int, default=2,
                     help="batches kept in flight (model lanes on separate HIP streams, as evaluate.py runs the "
                          "eval loop); 1 = one batch at a time. The serial figure is reported alongside.")
+    ap.add_argument("--input", default="f32", choices=["f32", "u8"],
+                    help="f32 = the reference's contract (normalised float32 NCHW, the headline); u8 = uint8 HWC images "
+                         "with ToTensor + Normalize fused into the stem (SURVEY 8f N1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--variant", default="small", choices=["small", "xsmall", "full", "valexnet"],
                     help="small = BASELINE.json configs[1] (the headline); the others are parity-test configs")
@@ -162,7 +165,15 @@ def main():
 
     B = args.batch
     n_total = B * world
-    x = torch.from_numpy(synth.synth_images(B, first=rank * B, hw=spec.image_hw)).to(dev)      # resident in HBM
+    if args.input == "u8":
+        if args.variant == "valexnet":
+            raise SystemExit("--input u8 is not available for the vAlexnet variant")
+        u8 = synth.synth_images_u8(B, first=rank * B, hw=spec.image_hw)
+        x = torch.from_numpy(np.ascontiguousarray(u8.transpose(0, 2, 3, 1))).to(dev)             # uint8 [B,H,W,3], resident in HBM
+        fwd = model.forward_u8
+    else:
+        x = torch.from_numpy(synth.synth_images(B, first=rank * B, hw=spec.image_hw)).to(dev)  # resident in HBM
+        fwd = model.forward
 
     R = max(1, args.inflight)
     if R > 1:
@@ -174,11 +185,11 @@ def main():
         lanes > 1, step i runs on lane i % lanes and its own stream, so consecutive steps overlap."""
         with torch.no_grad():
             if lanes == 1:
-                y = model(x)
+                y = fwd(x)
                 return all_gather_logits(y, n_total) if world > 1 else y
             lane = i % lanes
             with torch.cuda.stream(streams[lane]):
-                y = model(x, lane=lane)
+                y = fwd(x, lane=lane)
                 return all_gather_logits(y, n_total) if world > 1 else y
 
     def fence():
@@ -264,6 +275,8 @@ def main():
                                     f"bit-packed HIP LUT kernels (BASELINE.json configs[1])") if args.variant == "small"
                        else f"TT {args.variant} variant forward, batch={B} 224x224 per GPU (parity-test configuration)",
                        "batch_per_gpu": B, "global_batch": n_total, "batches_in_flight": R,
+                       "input": "float32 NCHW, normalised (the reference's contract)" if args.input == "f32"
+                       else "uint8 HWC, ToTensor + Normalize fused into the stem",
                        "parallelism": f"batch shard x{world}" + (" + RCCL all-gather of logits" if world > 1 else "")},
             "inflight": R,
             "serial": {"value": round(n_total * args.steps / elapsed_serial, 2),

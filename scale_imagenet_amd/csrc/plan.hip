@@ -111,6 +111,8 @@ struct ttnet_plan {
   // stem
   uint16_t *stem_wt = nullptr;      // fp16 x 2 split weights, fragment order
   float *stem_init = nullptr;       // accumulator start values (folded BN shift), 64 floats
+  uint32_t *norm_tab = nullptr;     // uint8 input: split pooled values per (channel, byte sum), stem_norm_table
+  float in_mean[3] = {0.485f, 0.456f, 0.406f}, in_std[3] = {0.229f, 0.224f, 0.225f};   // utils/preprocess.py:107-108
   // activations: x_rp[i] / x_cp[i] = input of block i
   std::vector<uint64_t *> x_rp;
   std::vector<uint16_t *> x_cp;
@@ -134,6 +136,7 @@ struct ttnet_plan {
     hipGraphNode_t first = nullptr, last = nullptr;     // the kernels that read x / write the logits
     // own copies of those two kernels' launch parameters (argument values in 8-byte slots)
     hipKernelNodeParams first_p{}, last_p{};
+    int first_nargs = 0;
     uint64_t first_argv[8] = {}, last_argv[8] = {};
     void *first_args[8] = {}, *last_args[8] = {};
     const void *x = nullptr;
@@ -480,6 +483,13 @@ void switch_lane(ttnet_plan *pl, int k) {
   pl->cur = k;
 }
 
+int upload_norm_table(ttnet_plan *pl) {
+  std::vector<uint32_t> tab(3 * 1024);
+  stem_norm_table(pl->in_mean, pl->in_std, tab.data());
+  TT_HIP(hipMemcpy(pl->norm_tab, tab.data(), tab.size() * 4, hipMemcpyHostToDevice));
+  return TTNET_OK;
+}
+
 int allocate(ttnet_plan *pl) {
   size_t *tb = &pl->table_bytes;
   const int kpad = (pl->inter + 15) / 16 * 16;
@@ -490,6 +500,8 @@ int allocate(ttnet_plan *pl) {
   } else {
     TT_TRY(dev_alloc(pl, &pl->stem_wt, stem_split_weights_elems(), false));
     TT_TRY(dev_alloc(pl, &pl->stem_init, 64, false));
+    TT_TRY(dev_alloc(pl, &pl->norm_tab, 3 * 1024, false));
+    TT_TRY(upload_norm_table(pl));
     TT_TRY(dev_alloc(pl, &pl->w1p, (size_t)pl->inter * pl->fcsize, false));
   }
   for (auto &mh : pl->blocks) {
@@ -917,17 +929,21 @@ int ttnet_plan_finalize(ttnet_plan *pl, void *stream) {
 
 namespace {
 
-int forward_eager(ttnet_plan *pl, const float *x_dev, int64_t n, float *logits_dev, hipStream_t s) {
+int forward_eager(ttnet_plan *pl, const void *x_dev, bool u8, int64_t n, float *logits_dev, hipStream_t s) {
   pl->timing_used = 0;
   if (pl->va) {
+    if (u8) {
+      set_error("uint8 input is not implemented for the vAlexnet variant");
+      return TTNET_E_UNSUPPORTED;
+    }
     TT_TIMED(pl, "va.stem", s,
-             launch_va_stem(x_dev, (const float *)pl->tensors["features.0.weight"].dev,
+             launch_va_stem((const float *)x_dev, (const float *)pl->tensors["features.0.weight"].dev,
                             (const float *)pl->tensors["features.0.bias"].dev, pl->va_scale, pl->va_shift, pl->x_rp[0],
                             (int)n, s));
     return run_va_tail(pl, (int)n, logits_dev, s);
   }
   TT_TIMED(pl, "stem", s,
-           launch_stem(x_dev, pl->stem_wt, pl->stem_init, pl->x_rp[0], pl->full ? nullptr : pl->x_cp[0], (int)n,
+           launch_stem(x_dev, u8, pl->norm_tab, pl->stem_wt, pl->stem_init, pl->x_rp[0], pl->full ? nullptr : pl->x_cp[0], (int)n,
                        pl->p, s));
   return run_from_blocks(pl, (int)n, logits_dev, s);
 }
@@ -937,7 +953,7 @@ int forward_eager(ttnet_plan *pl, const float *x_dev, int64_t n, float *logits_d
 // hipGraph captured on a private stream.  Only two pointers change between calls: the input
 // (argument 0 of the first kernel) and the logits (argument 4 of lin2, the last kernel); they
 // are patched into the instantiated graph when they differ from the previous call.
-constexpr int kFirstKernelArgs = 7, kLastKernelArgs = 8, kLastKernelOutArg = 4;
+constexpr int kFirstKernelArgs = 7, kLastKernelArgs = 8, kLastKernelOutArg = 4;   // (first: the leading 7 of stem_pc_kernel's 8)
 
 void drop_graph(ttnet_plan::GraphEntry &e) {
   if (e.exec) (void)hipGraphExecDestroy(e.exec);
@@ -963,10 +979,10 @@ bool own_params(hipGraphNode_t node, const int *sizes, int nargs, hipKernelNodeP
   return true;
 }
 
-bool capture_forward(ttnet_plan *pl, const float *x_dev, int64_t n, float *logits_dev, ttnet_plan::GraphEntry &e) {
+bool capture_forward(ttnet_plan *pl, const void *x_dev, bool u8, int64_t n, float *logits_dev, ttnet_plan::GraphEntry &e) {
   if (!pl->cap_stream && hipStreamCreateWithFlags(&pl->cap_stream, hipStreamNonBlocking) != hipSuccess) return false;
   if (hipStreamBeginCapture(pl->cap_stream, hipStreamCaptureModeThreadLocal) != hipSuccess) return false;
-  const int r = forward_eager(pl, x_dev, n, logits_dev, pl->cap_stream);
+  const int r = forward_eager(pl, x_dev, u8, n, logits_dev, pl->cap_stream);
   hipGraph_t g = nullptr;
   const hipError_t ee = hipStreamEndCapture(pl->cap_stream, &g);
   if (r != TTNET_OK || ee != hipSuccess || !g) {
@@ -995,10 +1011,11 @@ bool capture_forward(ttnet_plan *pl, const float *x_dev, int64_t n, float *logit
   if (hipGraphNodeGetType(e.first, &t0) != hipSuccess || hipGraphNodeGetType(e.last, &t1) != hipSuccess ||
       t0 != hipGraphNodeTypeKernel || t1 != hipGraphNodeTypeKernel || e.first == e.last)
     return false;
-  static const int first_sizes[7] = {8, 8, 8, 8, 8, 4, 4};        // stem_pc_kernel(x, wfrag, init, rp, cp, p, n)
+  static const int first_sizes[8] = {8, 8, 8, 8, 8, 4, 4, 8};     // stem_pc_kernel(x, wfrag, init, rp, cp, p, n, norm_tab)
   static const int first_sizes_va[7] = {8, 8, 8, 8, 8, 8, 4};     // va_stem_kernel(x, w, bias, scale, shift, rp, n)
   static const int last_sizes[8] = {8, 8, 8, 4, 8, 4, 4, 4};      // lin2_f16x2_kernel(A, B, bias, inv, out, M, N, KS)
-  if (!own_params(e.first, pl->va ? first_sizes_va : first_sizes, kFirstKernelArgs, e.first_p, e.first_argv, e.first_args) ||
+  e.first_nargs = pl->va ? 7 : 8;
+  if (!own_params(e.first, pl->va ? first_sizes_va : first_sizes, e.first_nargs, e.first_p, e.first_argv, e.first_args) ||
       !own_params(e.last, last_sizes, kLastKernelArgs, e.last_p, e.last_argv, e.last_args))
     return false;
   // the two slots that will be patched must hold exactly the pointers this capture ran with
@@ -1030,7 +1047,8 @@ int ttnet_plan_set_lanes(ttnet_plan *pl, int lanes) {
   return TTNET_OK;
 }
 
-int ttnet_forward_lane(ttnet_plan *pl, int lane, const float *x_dev, int64_t n, float *logits_dev, void *stream) {
+namespace {
+int forward_impl(ttnet_plan *pl, int lane, const void *x_dev, bool u8, int64_t n, float *logits_dev, void *stream) {
   TT_TRY(check_ready(pl, x_dev, n, logits_dev));
   if (lane < 0 || lane >= (int)pl->lanes.size()) {
     set_error("forward: lane %d but the plan has %d (ttnet_plan_set_lanes)", lane, (int)pl->lanes.size());
@@ -1043,32 +1061,33 @@ int ttnet_forward_lane(ttnet_plan *pl, int lane, const float *x_dev, int64_t n, 
   }
   ttnet_plan::Lane &L = pl->lanes[lane];
   hipStream_t s = (hipStream_t)stream;
-  if (pl->profiling || !pl->graphs_ok) return forward_eager(pl, x_dev, n, logits_dev, s);
+  if (pl->profiling || !pl->graphs_ok) return forward_eager(pl, x_dev, u8, n, logits_dev, s);
+  const int64_t key = 2 * n + (u8 ? 1 : 0);               // one graph per (batch size, input kind)
   hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
   if (s && hipStreamIsCapturing(s, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone)
-    return forward_eager(pl, x_dev, n, logits_dev, s);       // the caller is capturing us into a graph of their own
-  auto it = L.graphs.find(n);
+    return forward_eager(pl, x_dev, u8, n, logits_dev, s);   // the caller is capturing us into a graph of their own
+  auto it = L.graphs.find(key);
   if (it == L.graphs.end()) {
-    if (++L.eager_calls[n] <= 2) return forward_eager(pl, x_dev, n, logits_dev, s);   // warm: attributes, lazy module load
+    if (++L.eager_calls[key] <= 2) return forward_eager(pl, x_dev, u8, n, logits_dev, s);   // warm: attributes, lazy module load
     ttnet_plan::GraphEntry e;
-    if (!capture_forward(pl, x_dev, n, logits_dev, e)) {
+    if (!capture_forward(pl, x_dev, u8, n, logits_dev, e)) {
       drop_graph(e);
       pl->graphs_ok = false;                                   // stay on plain launches
       (void)hipGetLastError();
-      return forward_eager(pl, x_dev, n, logits_dev, s);
+      return forward_eager(pl, x_dev, u8, n, logits_dev, s);
     }
     if (L.graphs.size() >= 8) {                                // bound the cache: drop the smallest batch size
       drop_graph(L.graphs.begin()->second);
       L.graphs.erase(L.graphs.begin());
     }
-    it = L.graphs.emplace(n, e).first;
+    it = L.graphs.emplace(key, e).first;
   }
   ttnet_plan::GraphEntry &e = it->second;
   bool ok = true;
   if (e.x != x_dev) {
     e.first_argv[0] = (uint64_t)(uintptr_t)x_dev;
     e.first_p.kernelParams = e.first_args;          // (the entry may have been moved since capture)
-    for (int i = 0; i < kFirstKernelArgs; ++i) e.first_args[i] = &e.first_argv[i];
+    for (int i = 0; i < e.first_nargs; ++i) e.first_args[i] = &e.first_argv[i];
     ok = hipGraphExecKernelNodeSetParams(e.exec, e.first, &e.first_p) == hipSuccess;
     e.x = x_dev;
   }
@@ -1085,16 +1104,42 @@ int ttnet_forward_lane(ttnet_plan *pl, int lane, const float *x_dev, int64_t n, 
     L.graphs.erase(it);
     pl->graphs_ok = false;
     (void)hipGetLastError();
-    return forward_eager(pl, x_dev, n, logits_dev, s);
+    return forward_eager(pl, x_dev, u8, n, logits_dev, s);
   }
   pl->last_n = n;
   pl->timing_used = 0;
   pl->graph_replays++;
   return TTNET_OK;
 }
+}  // namespace
+
+int ttnet_forward_lane(ttnet_plan *pl, int lane, const float *x_dev, int64_t n, float *logits_dev, void *stream) {
+  return forward_impl(pl, lane, x_dev, false, n, logits_dev, stream);
+}
 
 int ttnet_forward(ttnet_plan *pl, const float *x_dev, int64_t n, float *logits_dev, void *stream) {
-  return ttnet_forward_lane(pl, 0, x_dev, n, logits_dev, stream);
+  return forward_impl(pl, 0, x_dev, false, n, logits_dev, stream);
+}
+
+int ttnet_forward_u8(ttnet_plan *pl, int lane, const uint8_t *x_nhwc_dev, int64_t n, float *logits_dev, void *stream) {
+  return forward_impl(pl, lane, x_nhwc_dev, true, n, logits_dev, stream);
+}
+
+int ttnet_plan_set_input_norm(ttnet_plan *pl, const float *mean3, const float *std3) {
+  if (!pl || !mean3 || !std3 || pl->va) {
+    set_error("set_input_norm: null argument (or the vAlexnet variant, which has no uint8 path)");
+    return TTNET_E_INVALID;
+  }
+  for (int c = 0; c < 3; ++c) {
+    if (!(std3[c] > 0.f)) {
+      set_error("set_input_norm: std[%d] = %g", c, (double)std3[c]);
+      return TTNET_E_INVALID;
+    }
+    pl->in_mean[c] = mean3[c];
+    pl->in_std[c] = std3[c];
+  }
+  (void)hipSetDevice(pl->device);
+  return upload_norm_table(pl);
 }
 
 int ttnet_forward_from_stem_bits(ttnet_plan *pl, const uint64_t *rows_dev, int64_t n, float *logits_dev,

@@ -94,13 +94,28 @@ __device__ inline void ballots4(uint32_t &klo, uint32_t &khi, uint32_t &cw, uint
 // indices are forced into SGPRs, border handling is a clamp of the load address plus a 0/4
 // multiplier instead of per-element selects, and everything that does not depend on the item is
 // computed once.
-__global__ __launch_bounds__(STEM_THREADS) void stem_pc_kernel(const float *__restrict__ x, const uint4 *__restrict__ wfrag,
+//
+// U8 = true: the input is the decoder's uint8 HWC image and the last two steps of
+// the input pipeline, ToTensor (/255) and Normalize(mean, std) (utils/preprocess.py:104-108),
+// are fused in front of the average pool: the four bytes of a pooled pixel and channel are summed
+// as integers (v_dot4 with a byte selector) and the sum (0..1020) indexes a table of already
+// split values  ((s/4)/255 - mean_c)/std_c x prescale  built on the host in float64.  A quarter of
+// the input bytes, fewer vector instructions; the value is the real-arithmetic one rounded once
+// (the float32 path rounds each pixel and each add: <= 2e-7 apart on a pooled value).
+template <bool U8>
+__global__ __launch_bounds__(STEM_THREADS) void stem_pc_kernel(const void *__restrict__ xin, const uint4 *__restrict__ wfrag,
                                                                const float *__restrict__ init, uint64_t *__restrict__ rp,
-                                                               uint16_t *__restrict__ cp, int p, int n_images) {
+                                                               uint16_t *__restrict__ cp, int p, int n_images,
+                                                               const uint32_t *__restrict__ norm_tab) {
+  const float *x = (const float *)xin;
+  const uint8_t *xu8 = (const uint8_t *)xin;
   extern __shared__ __align__(16) uint8_t smem[];
   uint16_t *tiles = (uint16_t *)smem;                               // [2][TILE] fp16
   uint32_t(*stage)[64][NT + 2] = (uint32_t(*)[64][NT + 2])(smem + 2 * TILE * 2);   // [2][64][NT+2]
   float *s_init = (float *)(smem + 2 * TILE * 2 + 2 * 64 * (NT + 2) * 4);          // [mtile][half][16] accumulator start values
+  uint32_t *s_norm = (uint32_t *)(s_init + 64);                                    // U8: [3][1024] h1 | h2 << 16
+  if constexpr (U8)
+    for (int i = threadIdx.x; i < 3 * 1024; i += STEM_THREADS) s_norm[i] = norm_tab[i];
   const int H = 224, W = 224;
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const bool producer = wave >= CONS_WAVES;
@@ -126,6 +141,19 @@ __global__ __launch_bounds__(STEM_THREADS) void stem_pc_kernel(const float *__re
     colc[k] = 2 * min(max(ix, 0), 111);
     colm[k] = (ix >= 0 && ix < 112) ? 0.25f * X_PRESCALE : 0.0f;     // average of four, prescale; 0 in the padding
   }
+  // U8: byte offset of the pooled pixel's two raw pixels (6 bytes: r g b r g b) in a raw row; mask
+  // of the padding columns
+  int colb[2];
+  uint32_t colk[2];
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int ix = lane + 64 * k - 3;
+    colb[k] = 6 * min(max(ix, 0), 111);
+    colk[k] = (ix >= 0 && ix < 112) ? 0xFFFFFFFFu : 0u;
+  }
+  constexpr int RPW8 = (TR + PROD_WAVES - 1) / PROD_WAVES;          // U8: pooled rows per producer wave (6), 3 channels each
+  typedef uint32_t __attribute__((aligned(2))) u32_a2;
+  uint32_t qa[RPW8][2][2], qb[RPW8][2][2];                          // [row][chunk][0: bytes 0-3, 1: bytes 4-5] of raw rows 2iy, 2iy+1
   // pooled tile row r = pooled image row 2*oy0 - 3 + r; a producer wave owns the (c, r) rows pw,
   // pw+4, ...  All global loads of an item are issued at once, one item ahead: they are in flight
   // across the workgroup barrier and while the row words of the previous item are emitted, so
@@ -136,6 +164,23 @@ __global__ __launch_bounds__(STEM_THREADS) void stem_pc_kernel(const float *__re
   auto issue_loads = [&](int item) {
     const int n = item / (56 / SR), oy0 = (item % (56 / SR)) * SR;
     const int pw = wave - CONS_WAVES;                   // 0..3
+    if constexpr (U8) {
+#pragma unroll
+      for (int bi = 0; bi < RPW8; ++bi) {
+        const int r = pw + PROD_WAVES * bi;             // wave-uniform
+        const int iy = 2 * oy0 - 3 + r;
+        const bool row_ok = r < TR && iy >= 0 && iy < 112;
+        const uint8_t *src_row = xu8 + ((size_t)n * H + 2 * (row_ok ? iy : 0)) * (W * 3);
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+          qa[bi][k][0] = *(const u32_a2 *)(src_row + colb[k]);
+          qa[bi][k][1] = *(const uint16_t *)(src_row + colb[k] + 4);
+          qb[bi][k][0] = *(const u32_a2 *)(src_row + W * 3 + colb[k]);
+          qb[bi][k][1] = *(const uint16_t *)(src_row + W * 3 + colb[k] + 4);
+        }
+      }
+      return;
+    }
 #pragma unroll
     for (int bi = 0; bi < RPW; ++bi) {
       const int cr = pw + PROD_WAVES * bi;              // wave-uniform
@@ -153,6 +198,38 @@ __global__ __launch_bounds__(STEM_THREADS) void stem_pc_kernel(const float *__re
   auto split_tile = [&](int item, uint16_t *tile) {
     const int oy0 = (item % (56 / SR)) * SR;
     const int pw = wave - CONS_WAVES;
+    if constexpr (U8) {
+#pragma unroll
+      for (int bi = 0; bi < RPW8; ++bi) {
+        const int r = pw + PROD_WAVES * bi;
+        if (r < TR) {
+          const int iy = 2 * oy0 - 3 + r;
+          const uint32_t rowk = (iy >= 0 && iy < 112) ? 0xFFFFFFFFu : 0u;     // wave-uniform
+          uint16_t *dst = tile + r * ROWP + lane;
+#pragma unroll
+          for (int k = 0; k < 2; ++k) {
+            if (lane + 64 * k < TW) {
+              const uint32_t a0 = qa[bi][k][0], a1 = qa[bi][k][1], b0 = qb[bi][k][0], b1 = qb[bi][k][1];
+              // bytes: a0 = r0 g0 b0 r1, a1 = g1 b1 (likewise the second raw row)
+              uint32_t sum[3];
+              sum[0] = __builtin_amdgcn_udot4(a0, 0x01000001u, __builtin_amdgcn_udot4(b0, 0x01000001u, 0u, false), false);
+              sum[1] = __builtin_amdgcn_udot4(a0, 0x00000100u, __builtin_amdgcn_udot4(b0, 0x00000100u, a1 & 0xFFu, false), false) +
+                       (b1 & 0xFFu);
+              sum[2] = __builtin_amdgcn_udot4(a0, 0x00010000u, __builtin_amdgcn_udot4(b0, 0x00010000u, a1 >> 8, false), false) +
+                       (b1 >> 8);
+              const uint32_t keep = colk[k] & rowk;
+#pragma unroll
+              for (int c = 0; c < 3; ++c) {
+                const uint32_t hh = s_norm[c * 1024 + sum[c]] & keep;            // zero padding after the normalisation
+                dst[c * TR * ROWP + 64 * k] = (uint16_t)hh;
+                dst[c * TR * ROWP + 64 * k + TW] = (uint16_t)(hh >> 16);
+              }
+            }
+          }
+        }
+      }
+      return;
+    }
 #pragma unroll
     for (int bi = 0; bi < RPW; ++bi) {
       const int cr = pw + PROD_WAVES * bi;
@@ -362,17 +439,35 @@ void stem_split_weights(const float *w, const double *scale, const double *shift
 
 size_t stem_split_weights_elems() { return (size_t)KSTEPS * NPL * 2 * 64 * 8; }
 
-int launch_stem(const float *x, const void *wfrag, const float *init, uint64_t *rp, uint16_t *cp, int n, int p,
-                hipStream_t s) {
+// U8 input: table [3][1024] of split pooled values, indexed by the integer sum of the four bytes
+void stem_norm_table(const float mean[3], const float stdv[3], uint32_t *tab) {
+  for (int c = 0; c < 3; ++c)
+    for (int sidx = 0; sidx < 1024; ++sidx) {
+      const double v = ((((double)sidx / 4.0) / 255.0) - (double)mean[c]) / (double)stdv[c] * (double)X_PRESCALE;
+      const float vf = sidx <= 1020 ? (float)v : 0.f;
+      const uint16_t h1 = f32_to_f16_rne(vf);
+      const uint16_t h2 = f32_to_f16_rne(vf - f16_to_f32(h1));
+      tab[c * 1024 + sidx] = (uint32_t)h1 | ((uint32_t)h2 << 16);
+    }
+}
+
+int launch_stem(const void *x, bool x_is_u8, const uint32_t *norm_tab, const void *wfrag, const float *init, uint64_t *rp,
+                uint16_t *cp, int n, int p, hipStream_t s) {
   if (p < 1 || p > 64 || (cp && p != 64)) {
     set_error("stem: p=%d outside [1,64] (channel words need p = 64)", p);
     return TTNET_E_UNSUPPORTED;
   }
-  const size_t lds = (size_t)2 * TILE * 2 + (size_t)2 * 64 * (NT + 2) * 4 + 64 * 4;
-  TT_TRY(ensure_dynamic_lds((const void *)stem_pc_kernel, lds));
+  const size_t lds = (size_t)2 * TILE * 2 + (size_t)2 * 64 * (NT + 2) * 4 + 64 * 4 + (x_is_u8 ? 3 * 1024 * 4 : 0);
   const int items = n * (56 / SR);
-  hipLaunchKernelGGL(stem_pc_kernel, dim3(std::min(items, 256)), dim3(STEM_THREADS), lds, s, x, (const uint4 *)wfrag, init, rp,
-                     cp, p, n);
+  if (x_is_u8) {
+    TT_TRY(ensure_dynamic_lds((const void *)stem_pc_kernel<true>, lds));
+    hipLaunchKernelGGL(stem_pc_kernel<true>, dim3(std::min(items, 256)), dim3(STEM_THREADS), lds, s, x, (const uint4 *)wfrag, init,
+                       rp, cp, p, n, norm_tab);
+  } else {
+    TT_TRY(ensure_dynamic_lds((const void *)stem_pc_kernel<false>, lds));
+    hipLaunchKernelGGL(stem_pc_kernel<false>, dim3(std::min(items, 256)), dim3(STEM_THREADS), lds, s, x, (const uint4 *)wfrag,
+                       init, rp, cp, p, n, norm_tab);
+  }
   TT_HIP(hipGetLastError());
   return TTNET_OK;
 }

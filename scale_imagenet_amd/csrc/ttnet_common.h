@@ -135,7 +135,10 @@ float weight_prescale(const float *w, size_t n);
 // stem.hip
 // wfrag: the conv weights (BN scale folded in) split into two fp16 planes in MFMA fragment order;
 // init[64]: accumulator start values = the folded BN shift (both from stem_split_weights)
-int launch_stem(const float *x, const void *wfrag, const float *init, uint64_t *rp, uint16_t *cp, int n, int p, hipStream_t s);
+// x: float32 NCHW, or (x_is_u8) uint8 NHWC with the normalisation table of stem_norm_table
+int launch_stem(const void *x, bool x_is_u8, const uint32_t *norm_tab, const void *wfrag, const float *init, uint64_t *rp,
+                uint16_t *cp, int n, int p, hipStream_t s);
+void stem_norm_table(const float mean[3], const float stdv[3], uint32_t *tab /*[3][1024]*/);
 void stem_split_weights(const float *w /*[p][3][7][7]*/, const double *scale, const double *shift, int p, uint16_t *out,
                         float *init /*[64]*/);
 size_t stem_split_weights_elems();

@@ -243,6 +243,7 @@ class _TTNetBase(nn.Module):
             plan = _Plan(self.spec, self.args, idx, max(n, self.DEFAULT_MAX_BATCH))
             if self.__dict__.get("_lanes", 1) > 1:
                 plan.set_lanes(self._lanes)
+            self._apply_input_norm(plan)
             self._plans[idx] = plan
         sig = self._state_signature()
         if plan.signature != sig:
@@ -286,6 +287,35 @@ class _TTNetBase(nn.Module):
         _lib.check(plan.lib.ttnet_forward_lane(plan.handle, int(lane), C.c_void_p(x.data_ptr()), n,
                                                C.c_void_p(out.data_ptr()), C.c_void_p(stream)))
         return out
+
+    def forward_u8(self, x_u8: torch.Tensor, lane: int = 0) -> torch.Tensor:
+        """Forward from the decoder's uint8 HWC images ``[N,H,W,3]``: ToTensor + Normalize
+        (utils/preprocess.py:104-108) are applied inside the stem kernel."""
+        if self.training:
+            raise RuntimeError("the HIP path implements eval-mode inference only: call model.eval()")
+        h, w = self.spec.image_hw
+        if (not x_u8.is_cuda) or x_u8.dtype != torch.uint8 or x_u8.dim() != 4 or tuple(x_u8.shape[1:]) != (h, w, 3):
+            raise RuntimeError(f"expected a uint8 HIP tensor [N,{h},{w},3], got {x_u8.dtype} {tuple(x_u8.shape)} on {x_u8.device}")
+        x_u8 = x_u8.contiguous()
+        n = x_u8.shape[0]
+        plan = self._plan_for(x_u8.device, n)
+        out = torch.empty((n, self.spec.n_classes), device=x_u8.device, dtype=torch.float32)
+        stream = torch.cuda.current_stream(x_u8.device).cuda_stream
+        _lib.check(plan.lib.ttnet_forward_u8(plan.handle, int(lane), C.c_void_p(x_u8.data_ptr()), n,
+                                             C.c_void_p(out.data_ptr()), C.c_void_p(stream)))
+        return out
+
+    def set_input_norm(self, mean, std):
+        """Normalisation constants of ``forward_u8`` (default: the ImageNet ones)."""
+        self.__dict__["_input_norm"] = (tuple(float(v) for v in mean), tuple(float(v) for v in std))
+        for plan in self._plans.values():
+            self._apply_input_norm(plan)
+        return self
+
+    def _apply_input_norm(self, plan):
+        norm = self.__dict__.get("_input_norm")
+        if norm is not None:
+            _lib.check(plan.lib.ttnet_plan_set_input_norm(plan.handle, (C.c_float * 3)(*norm[0]), (C.c_float * 3)(*norm[1])))
 
     # -- parity taps (replace Block_TT.input_layer / output_layer, TT_FHE_SMALL.py:310,319) --
     def forward_from_stem_bits(self, rows: torch.Tensor) -> torch.Tensor:

@@ -316,6 +316,47 @@ def test_lanes_in_flight_match_lane0(dev):
     assert (a.loss, a.top1, a.top5, a.images) == (b.loss, b.top1, b.top5, b.images)
 
 
+def test_uint8_input_fused_normalise(model, variant, dev):
+    """uint8 HWC input with ToTensor + Normalize fused into the stem.  Bits equal
+    (pre >= 0) of the float64 oracle on the normalised float32 tensor outside the near-tie band;
+    where the stem bits agree with the float32-input path, the logits are identical."""
+    spec, st = spec_and_state(variant)
+    n = 16
+    u8 = synth.synth_images_u8(n)
+    xf = synth.normalize_u8(u8)
+    x_u8 = torch.from_numpy(np.ascontiguousarray(u8.transpose(0, 2, 3, 1))).to(dev)
+    with torch.no_grad():
+        y_f = model(torch.from_numpy(xf).to(dev)).clone()
+        rows_f = model.read_stage("features.3", n).copy()
+        for _ in range(4):                         # plain launches, then the captured graph
+            y_u = model.forward_u8(x_u8).clone()
+        rows_u = model.read_stage("features.3", n).copy()
+    pre = OB.stem_pre64(xf, st)
+    bits = OB.unpack_rows(rows_u, 56)
+    bad = np.argwhere(bits != (pre >= 0).astype(np.uint8))
+    worst = max((abs(pre[tuple(d)]) for d in bad), default=0.0)
+    print(f"{variant} uint8 stem: {len(bad)} of {bits.size} bits differ from float64, largest |pre| there {worst:.2e}")
+    assert worst < OB.NEAR_TIE
+    same = (rows_u == rows_f).reshape(n, -1).all(axis=1)
+    assert same.sum() >= n - 2
+    assert torch.equal(y_u[torch.from_numpy(same).to(dev)], y_f[torch.from_numpy(same).to(dev)])
+    # other constants: mean 0 / std 1 is plain ToTensor
+    model.set_input_norm((0.0, 0.0, 0.0), (1.0, 1.0, 1.0))
+    try:
+        x01 = (u8[:2].astype(np.float32) / np.float32(255.0)).astype(np.float32)
+        with torch.no_grad():
+            model.forward_u8(x_u8[:2])
+            r_u = model.read_stage("features.3", 2).copy()
+        p01 = OB.stem_pre64(x01, st)
+        b01 = OB.unpack_rows(r_u, 56)
+        bad = np.argwhere(b01 != (p01 >= 0).astype(np.uint8))
+        assert max((abs(p01[tuple(d)]) for d in bad), default=0.0) < OB.NEAR_TIE
+    finally:
+        model.set_input_norm(synth.IMAGENET_MEAN, synth.IMAGENET_STD)
+    with pytest.raises(RuntimeError):
+        model.forward_u8(x_u8.permute(0, 3, 1, 2).contiguous())          # CHW is not the contract
+
+
 def test_majority_and_padding_edges(model, variant, dev):
     """Edge inputs of the integer path: all-zero and all-one stem bits, checked against the
     bit oracle with the GPU's own tables."""
