@@ -239,6 +239,49 @@ def reference_truth_table(block_tt_module, b) -> np.ndarray:
     return res.astype(np.float32) if b.last else res.astype(np.uint8)
 
 
+def gen_export_golden(n_filters: int = 12):
+    """tests/golden/ref_export_xsmall.json: what the reference's own exporter
+    (Block_TT.get_TT_block_1filter -> for_1_filter / save_cnf_dnf, models/TT_FHE_SMALL.py:344-431)
+    writes for the first filters of features.4.Block_conv1 of the x-small model (n = 4 inputs,
+    one of the sizes its get_expresion_methode1 handles).  The exporter's first step
+    (get_TT_block_all_filter) returns a small map for a padded block; its centre entry is the
+    window that covers the enumerated pattern (see reference_truth_table), and that [2^n, C]
+    table is handed to the reference's own per-filter code unchanged."""
+    import tempfile
+    variant = "xsmall"
+    spec = make_spec(variant, **{k: v for k, v in VARIANT_ARGS[variant].items() if k != "layers"})
+    st = synth.synth_state_dict(spec)
+    m = import_reference(variant)
+    m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in st.items()}, strict=True)
+    m.eval()
+    blk = spec.blocks[0].conv1
+    mod = m.features[4].Block_conv1
+    tab = reference_truth_table(mod, blk)                 # [G, 2^n, 1] bits; also sets mod.df / mod.n
+    mod.res_numpy = tab[:, :, 0].T.astype(np.float32)     # [2^n, C] as the exporter keeps it
+    out = {"block": blk.name, "n": int(blk.fan_in_bits), "blockici": 0, "sousblockici": 1, "filters": {}}
+    with tempfile.TemporaryDirectory() as d:
+        for f in range(n_filters):
+            before = set(os.listdir(d))
+            with contextlib.redirect_stdout(io.StringIO()):
+                mod.blockici, mod.sousblockici = 0, 1
+                cnf, dnf, cnf3 = mod.get_TT_block_1filter(f, d + os.sep)
+            files = {}
+            for name in sorted(set(os.listdir(d)) - before):
+                if name.endswith(".npy"):
+                    continue                              # 2^n x 2^n chararray of a constant filter: not reproduced
+                with open(os.path.join(d, name)) as fh:
+                    files[name] = fh.read()
+            out["filters"][str(f)] = {"column": tab[f, :, 0].astype(int).tolist(),
+                                      "dnf": None if dnf is None else str(dnf), "cnf": None if cnf is None else str(cnf),
+                                      "cnf_with_y": None if cnf3 is None else str(cnf3), "files": files}
+    import sympy, pandas
+    out["sympy"], out["pandas"] = sympy.__version__, pandas.__version__
+    with open(os.path.join(GOLD, "ref_export_xsmall.json"), "w") as fh:
+        json.dump(out, fh, indent=0)
+    print(f"[export] {len(out['filters'])} filters of {blk.name}: "
+          f"{sum(1 for v in out['filters'].values() if v['dnf'])} with expressions")
+
+
 def main(variants):
     os.makedirs(GOLD, exist_ok=True)
     torch.set_num_threads(8)
@@ -359,4 +402,8 @@ def main(variants):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1:] or ["small", "xsmall", "full", "valexnet"])
+    if sys.argv[1:] == ["export"]:
+        gen_export_golden()
+    else:
+        main(sys.argv[1:] or ["small", "xsmall", "full", "valexnet"])
+        gen_export_golden()

@@ -305,6 +305,13 @@ class _TTNetBase(nn.Module):
                                              C.c_void_p(out.data_ptr()), C.c_void_p(stream)))
         return out
 
+    def export_truth_tables(self, block_name: str, out_dir: str, block: int = 0, sub_block: int = 0, filters=None,
+                            max_expr_bits: int = 9):
+        """Write the reference's truth-table files (CSV, DNF / CNF, SAT form) for one
+        ``Block_TT`` from the table the plan built on the GPU.  See ``scale_imagenet_amd.export``."""
+        from . import export
+        return export.export_block(self.get_table(block_name), out_dir, block, sub_block, filters, max_expr_bits)
+
     def set_input_norm(self, mean, std):
         """Normalisation constants of ``forward_u8`` (default: the ImageNet ones)."""
         self.__dict__["_input_norm"] = (tuple(float(v) for v in mean), tuple(float(v) for v in std))

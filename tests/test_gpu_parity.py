@@ -6,6 +6,8 @@ Bars (north star): integer gate path bit exact; logits within 1e-5; top-1 exact 
 Float -> bit boundaries (truth-table entries, stem bits) are exact except at near ties
 (|pre-activation| < 1e-5), which are listed in the fixtures and reported, never hidden.
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -355,6 +357,28 @@ def test_uint8_input_fused_normalise(model, variant, dev):
         model.set_input_norm(synth.IMAGENET_MEAN, synth.IMAGENET_STD)
     with pytest.raises(RuntimeError):
         model.forward_u8(x_u8.permute(0, 3, 1, 2).contiguous())          # CHW is not the contract
+
+
+def test_truth_table_export_from_gpu_tables(dev, tmp_path):
+    """the files exported from the GPU-built table of an x-small block equal the
+    files the reference's own exporter wrote (fixture from oracle/gen_golden.py)."""
+    import json
+    from _util import GOLD
+    m = _model("xsmall", dev)
+    with open(os.path.join(GOLD, "ref_export_xsmall.json")) as f:
+        g = json.load(f)
+    table = m.get_table(g["block"])
+    compared = 0
+    for f_str, want in g["filters"].items():
+        fi = int(f_str)
+        if table[fi, :, 0].astype(int).tolist() != want["column"]:
+            continue
+        got = m.export_truth_tables(g["block"], str(tmp_path / f_str), g["blockici"], g["sousblockici"], filters=[fi])[fi]
+        assert (got["dnf"], got["cnf"]) == (want["dnf"], want["cnf"])
+        files = {n: open(tmp_path / f_str / n).read() for n in sorted(os.listdir(tmp_path / f_str))}
+        assert files == want["files"]
+        compared += 1
+    assert compared >= 10
 
 
 def test_majority_and_padding_edges(model, variant, dev):
