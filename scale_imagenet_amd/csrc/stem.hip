@@ -113,7 +113,12 @@ __global__ __launch_bounds__(STEM_THREADS) void stem_pc_kernel(const void *__res
   uint16_t *tiles = (uint16_t *)smem;                               // [2][TILE] fp16
   uint32_t(*stage)[64][NT + 2] = (uint32_t(*)[64][NT + 2])(smem + 2 * TILE * 2);   // [2][64][NT+2]
   float *s_init = (float *)(smem + 2 * TILE * 2 + 2 * 64 * (NT + 2) * 4);          // [mtile][half][16] accumulator start values
-  uint32_t *s_norm = (uint32_t *)(s_init + 64);                                    // U8: [3][1024] h1 | h2 << 16
+  uint4 *s_w = (uint4 *)(s_init + 64);                                             // weight fragments [ks][plane][mtile][lane]
+  uint32_t *s_norm = (uint32_t *)(s_w + KSTEPS * NPL * 2 * 64);                    // U8: [3][1024] h1 | h2 << 16
+  // The weight fragments (44 KiB) stay in LDS for the life of the workgroup: fetched from L2 every
+  // k-step they put an L2 round trip (under the producers' HBM traffic) on each of the 11 k-steps
+  // of every item -- the matrix pipe then idled for half of the MFMA phase.
+  for (int i = threadIdx.x; i < KSTEPS * NPL * 2 * 64; i += STEM_THREADS) s_w[i] = wfrag[i];
   if constexpr (U8)
     for (int i = threadIdx.x; i < 3 * 1024; i += STEM_THREADS) s_norm[i] = norm_tab[i];
   const int H = 224, W = 224;
@@ -286,10 +291,10 @@ __global__ __launch_bounds__(STEM_THREADS) void stem_pc_kernel(const void *__res
 #pragma unroll
     for (int i = 0; i < UPW; ++i) acc[i] = start;
     const uint32_t *tile32 = (const uint32_t *)tile;
-    // weights in fragment order [ks][plane][mtile][lane] x 16 bytes, fetched one k-step ahead
+    // weights in fragment order [ks][plane][mtile][lane] x 16 bytes (LDS), read one k-step ahead
     uint4 aw_next[NPL];
 #pragma unroll
-    for (int pl = 0; pl < NPL; ++pl) aw_next[pl] = wfrag[(pl * 2 + m) * 64 + lane];
+    for (int pl = 0; pl < NPL; ++pl) aw_next[pl] = s_w[(pl * 2 + m) * 64 + lane];
 #pragma unroll 1
     for (int ks = 0; ks < KSTEPS; ++ks) {
       uint4 aw[NPL];
@@ -297,7 +302,7 @@ __global__ __launch_bounds__(STEM_THREADS) void stem_pc_kernel(const void *__res
       for (int pl = 0; pl < NPL; ++pl) aw[pl] = aw_next[pl];
       if (ks + 1 < KSTEPS) {
 #pragma unroll
-        for (int pl = 0; pl < NPL; ++pl) aw_next[pl] = wfrag[(((ks + 1) * NPL + pl) * 2 + m) * 64 + lane];
+        for (int pl = 0; pl < NPL; ++pl) aw_next[pl] = s_w[(((ks + 1) * NPL + pl) * 2 + m) * 64 + lane];
       }
       int R = 2 * ks + h;                    // (c,kh) row of this half-wave's 8 k values
       if (R > 20) R = 20;                    // zero-weight pad row: any finite data
@@ -372,9 +377,11 @@ __global__ __launch_bounds__(STEM_THREADS) void stem_pc_kernel(const void *__res
     __syncthreads();
     for (int j = 0; j < my_items; ++j) {
       const int item = first + j * g;
-      if (j > 0) emit_rows(item - g, stage[(j - 1) & 1]);
+      // split first (its loads were issued most of a period ago), refill the load registers at
+      // once, and only then the row words of the previous item: the loads get ~3/4 of a period
       if (j + 1 < my_items) split_tile(item + g, tiles + ((j + 1) & 1) * TILE);
       if (j + 2 < my_items) issue_loads(item + 2 * g);
+      if (j > 0) emit_rows(item - g, stage[(j - 1) & 1]);
       __syncthreads();
     }
     if (my_items > 0) emit_rows(first + (my_items - 1) * g, stage[(my_items - 1) & 1]);
@@ -457,7 +464,8 @@ int launch_stem(const void *x, bool x_is_u8, const uint32_t *norm_tab, const voi
     set_error("stem: p=%d outside [1,64] (channel words need p = 64)", p);
     return TTNET_E_UNSUPPORTED;
   }
-  const size_t lds = (size_t)2 * TILE * 2 + (size_t)2 * 64 * (NT + 2) * 4 + 64 * 4 + (x_is_u8 ? 3 * 1024 * 4 : 0);
+  const size_t lds = (size_t)2 * TILE * 2 + (size_t)2 * 64 * (NT + 2) * 4 + 64 * 4 + (size_t)KSTEPS * NPL * 2 * 64 * 16 +
+                     (x_is_u8 ? 3 * 1024 * 4 : 0);
   const int items = n * (56 / SR);
   if (x_is_u8) {
     TT_TRY(ensure_dynamic_lds((const void *)stem_pc_kernel<true>, lds));
