@@ -59,7 +59,7 @@ CALIB_IMAGES = 64
 CALIB_FIRST = 100000      # calibration images are disjoint from every test batch
 
 
-def import_reference(variant: str):
+def import_reference(variant: str, layers: int = None):
     for name in ("torchvision", "torchvision.transforms", "torchvision.utils", "torchvision.datasets"):
         sys.modules.setdefault(name, types.ModuleType(name))
     sys.modules["torchvision"].transforms = sys.modules["torchvision.transforms"]
@@ -76,7 +76,10 @@ def import_reference(variant: str):
             from models.TT_general_imagenet_v2_xsmall import TT_vf_19lv3_imgnet_xsmall as M
         else:
             from models.TT_general_imagenet_v2 import TT_vf_19lv3_imgnet as M
-        m = M(Namespace(groups=[1, None, 4, None], **VARIANT_ARGS[variant])).eval()
+        a = dict(VARIANT_ARGS[variant])
+        if layers is not None:
+            a["layers"] = layers
+        m = M(Namespace(groups=[1, None, 4, None], **a)).eval()
     return m
 
 
@@ -282,6 +285,42 @@ def gen_export_golden(n_filters: int = 12):
           f"{sum(1 for v in out['filters'].values() if v['dnf'])} with expressions")
 
 
+def gen_depth_golden(layers: int, n: int = 2):
+    """tests/golden/ref_small_l<layers>.npz: --layers 3 / 4 of TT-small (a stride-1 first block,
+    TT_general_imagenet_v2_small.py:178-181, :95-96) on n synthetic images -- the reference's logits
+    and per-stage hashes; also asserts oracle/ttnet_float.py == reference bit for bit."""
+    spec = make_spec("small", 8, 8, layers)
+    m = import_reference("small", layers)
+    layout = state_dict_layout(spec)
+    assert list(m.state_dict().keys()) == list(layout.keys()), "state_dict key order differs"
+    st = synth.synth_state_dict(spec, calibrated=False)
+    sd = OF.to_torch_state(st)
+    m.load_state_dict(sd, strict=True)
+    x = torch.from_numpy(synth.synth_images(n))
+    ref_taps = {}
+    feats = m.features
+    hooks = [feats[3].register_forward_hook(lambda mod, inp, out: ref_taps.__setitem__("features.3", out.detach().clone()))]
+    for i, blk in enumerate(spec.blocks):
+        hooks.append(feats[4 + i].register_forward_hook(
+            lambda mod, inp, out, name=blk.name: ref_taps.__setitem__(name, out.detach().clone())))
+    with torch.no_grad():
+        y_ref = m(x)
+    for h in hooks:
+        h.remove()
+    taps = {}
+    y = OF.forward(x, sd, spec, taps)
+    assert torch.equal(y, y_ref), f"layers={layers}: oracle logits differ from the reference"
+    stages = {}
+    for k in ["features.3"] + [b.name for b in spec.blocks[:-1]]:
+        assert torch.equal(taps[k], ref_taps[k]), (layers, k)
+        stages[k] = sha(OB.pack_rows(ref_taps[k].numpy().astype(np.uint8)))
+    np.savez_compressed(os.path.join(GOLD, f"ref_small_l{layers}.npz"), logits=y_ref.numpy(), n_images=n,
+                        stage_names=np.array(list(stages.keys())), stage_sha=np.array(list(stages.values())),
+                        n_keys=len(layout))
+    print(f"[small --layers {layers}] oracle == reference on {n} images; {len(layout)} state keys; "
+          f"shapes {[tuple(ref_taps[b.name].shape[1:]) for b in spec.blocks]}")
+
+
 def main(variants):
     os.makedirs(GOLD, exist_ok=True)
     torch.set_num_threads(8)
@@ -404,6 +443,11 @@ def main(variants):
 if __name__ == "__main__":
     if sys.argv[1:] == ["export"]:
         gen_export_golden()
+    elif sys.argv[1:2] == ["depth"]:
+        for L in [int(a) for a in sys.argv[2:]] or [3, 4]:
+            gen_depth_golden(L)
     else:
         main(sys.argv[1:] or ["small", "xsmall", "full", "valexnet"])
         gen_export_golden()
+        for L in (3, 4):
+            gen_depth_golden(L)

@@ -166,8 +166,8 @@ def multihead_block_bits(x: np.ndarray, luts: Dict[str, np.ndarray], blk: MultiH
     out3 = run(x, blk.conv3)
     out2 = run(x, blk.conv2)
     out1 = run(x, blk.conv1)
-    out4 = majority2x2(x)
-    out3 = majority2x2(out3)
+    out4 = majority2x2(x) if blk.stride == 2 else x              # :91-96
+    out3 = majority2x2(out3) if blk.stride == 2 else out3
     p1, p2, p34 = pad_table(variant)[x.shape[-1]]
     out1, out2, out3, out4 = _zpad(out1, p1), _zpad(out2, p2), _zpad(out3, p34), _zpad(out4, p34)
     if taps is not None:

@@ -71,13 +71,15 @@ def block_tt(x: torch.Tensor, sd: Dict[str, torch.Tensor], b: BlockTTSpec,
 
 def multihead_block(x: torch.Tensor, sd: Dict[str, torch.Tensor], blk: MultiHeadSpec, variant: str,
                     taps: Optional[Dict[str, torch.Tensor]] = None) -> torch.Tensor:
-    """models/TT_general_imagenet_v2_small.py:78-148 (stride-2 path)."""
+    """models/TT_general_imagenet_v2_small.py:78-148."""
     out3 = block_tt(x, sd, blk.conv3)                                           # :88
     out2 = block_tt(x, sd, blk.conv2)                                           # :89
     out1 = block_tt(x, sd, blk.conv1)                                           # :90
-    assert blk.stride == 2
-    out4 = binarize01_thresholded(F.avg_pool2d(x, 2) - 0.5)                     # :93
-    out3 = binarize01_thresholded(F.avg_pool2d(out3, 2) - 0.5)                  # :94
+    if blk.stride == 2:
+        out4 = binarize01_thresholded(F.avg_pool2d(x, 2) - 0.5)                 # :93
+        out3 = binarize01_thresholded(F.avg_pool2d(out3, 2) - 0.5)              # :94
+    else:
+        out4 = x                                                                # :96
     w = x.shape[-1]
     tbl = pad_table(variant)
     if w not in tbl:

@@ -59,24 +59,28 @@ __device__ inline uint32_t row_field(uint32_t lo, uint32_t hi) {
   else return __builtin_amdgcn_alignbit(hi, lo, SH) & mask;
 }
 
-// One output row per lane, all WO columns: first every window index and its table read are
-// issued (WO independent ds_reads in flight), then the bits are balloted column by column.
+// One output row per lane, all WO columns, 16 columns at a time: first the window indices and
+// table reads of the chunk are issued (independent ds_reads in flight), then the bits are
+// balloted column by column.  (Used by the stride-1 blocks of --layers 3/4: 57 / 30 columns.)
 template <int KH, int KW, int STRIDE, int WO>
 __device__ inline void dw_row(const uint32_t (&lo)[KH], const uint32_t (&hi)[KH], const uint32_t *tab32, uint32_t c,
                               uint32_t &keep_lo, uint32_t &keep_hi) {
-  uint32_t word[WO], sel[WO];
-  static_for<0, WO>([&](auto ox) {
-    constexpr int OX = decltype(ox)::value;
-    uint32_t idx = 0;
+  static_for<0, (WO + 15) / 16>([&](auto chunk) {
+    constexpr int C0 = decltype(chunk)::value * 16, N = (WO - C0) < 16 ? (WO - C0) : 16;
+    uint32_t word[N], sel[N];
+    static_for<0, N>([&](auto i) {
+      constexpr int I = decltype(i)::value, OX = C0 + I;
+      uint32_t idx = 0;
 #pragma unroll
-    for (int kh = 0; kh < KH; ++kh) idx |= row_field<OX * STRIDE, KW>(lo[kh], hi[kh]) << (kh * KW);
-    sel[OX] = idx;
-    word[OX] = tab32[((idx >> 5) << 4) + c];      // striped table: dword w of channel c at [w*16 + c]
-  });
-  static_for<0, WO>([&](auto ox) {
-    constexpr int OX = decltype(ox)::value;
-    const uint64_t m = __ballot((word[OX] >> (sel[OX] & 31)) & 1u);
-    writelane64<OX>(keep_lo, keep_hi, m);
+      for (int kh = 0; kh < KH; ++kh) idx |= row_field<OX * STRIDE, KW>(lo[kh], hi[kh]) << (kh * KW);
+      sel[I] = idx;
+      word[I] = tab32[((idx >> 5) << 4) + c];      // striped table: dword w of channel c at [w*16 + c]
+    });
+    static_for<0, N>([&](auto i) {
+      constexpr int I = decltype(i)::value, OX = C0 + I;
+      const uint64_t m = __ballot((word[I] >> (sel[I] & 31)) & 1u);
+      writelane64<OX>(keep_lo, keep_hi, m);
+    });
   });
 }
 
@@ -243,6 +247,36 @@ __global__ __launch_bounds__(kGateThreads) void gate_stage1_kernel(GateBlockArgs
     stage_lds_async(lds, (const uint8_t *)(a.t_c3 + (size_t)q * 65536), kTableLds);
     wait_lds_stage();
     const uint16_t *tab = (const uint16_t *)lds;
+    if constexpr (STRIDE == 1) {
+      // stride-1 block (:95-96): out3 = conv3(x), out4 = x, both at the input size, written at the
+      // branch-padding offset (the zero border of the HO x WO planes is never touched)
+      constexpr int per = H * W, U = 4;
+      const int tasks = (n1 - n0) * per;
+      for (int t0 = threadIdx.x; t0 < tasks; t0 += U * kGateThreads) {
+        uint32_t w[U];
+        size_t dst[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int t = t0 + u * kGateThreads;
+          const bool live = t < tasks;
+          const int tt = live ? t : 0;
+          const int n = n0 + tt / per, r = tt % per, y = r / W, x = r % W;
+          w[u] = a.x_cp[(((size_t)n * Q + q) * H + y) * W + x];
+          dst[u] = live ? (((size_t)n * Q + q) * HO + y + a.off34) * WO + x + a.off34 : (size_t)-1;
+        }
+        uint32_t r[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) r[u] = tab[w[u]];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          if (dst[u] != (size_t)-1) {
+            a.o3[dst[u]] = (uint16_t)r[u];
+            a.o4[dst[u]] = (uint16_t)w[u];
+          }
+        }
+      }
+      return;
+    }
     constexpr int HP = H / 2, WP = W / 2, per = HP * WP, U = 4;
     const int tasks = (n1 - n0) * per;
     // U pooled pixels per thread and trip: 4U global loads, then 4U table reads, in flight together
@@ -276,13 +310,13 @@ __global__ __launch_bounds__(kGateThreads) void gate_stage1_kernel(GateBlockArgs
 }
 
 // lane K of (klo,khi) := ballot of bit K of r, for K = 0..15
-template <int K>
+template <int K, int NB = 16>
 struct BitBallots {
   __device__ static inline void run(uint32_t r, uint32_t &klo, uint32_t &khi) {
-    if constexpr (K < 16) {
+    if constexpr (K < NB) {
       const uint64_t m = __ballot((r >> K) & 1u);
       writelane64<K>(klo, khi, m);
-      BitBallots<K + 1>::run(r, klo, khi);
+      BitBallots<K + 1, NB>::run(r, klo, khi);
     }
   }
 };
@@ -293,14 +327,18 @@ struct BitBallots {
 // nib(out3)<<8 | nib(out4)<<12, each nibble LSB = channel 4g.  Two groups (2 x 64 KiB of
 // 8-bit entries) per workgroup produce one output channel word; the row layout of the same
 // 16 channels comes from 16 ballots (a wave covers whole image rows).
-template <int HO>
+// CG = output bits per convf group: 8 (Cout = 2C: two groups fill one 16-channel output word), or 4
+// for the stride-1 block of --layers 4 whose convf keeps the channel count (Cout = C: the two
+// groups of a workgroup fill one byte of an output word).
+template <int HO, int CG = 8>
 __global__ __launch_bounds__(kGateThreads) void gate_pf_kernel(GateBlockArgs a, const uint8_t *t_cf, uint16_t *out_cp,
                                                               uint64_t *out_rp, int slices) {
   extern __shared__ __align__(16) uint8_t lds[];
   constexpr int WO = HO;
-  constexpr int LPR = WO <= 16 ? 16 : 32, RPW = 64 / LPR, chunks = (HO + RPW - 1) / RPW;
+  constexpr int LPR = WO <= 16 ? 16 : (WO <= 32 ? 32 : 64), RPW = 64 / LPR, chunks = (HO + RPW - 1) / RPW;
+  constexpr uint64_t row_mask = LPR == 64 ? ~0ull : ((1ull << (LPR & 63)) - 1ull);
   const int j = blockIdx.x;              // output word; groups 2j, 2j+1
-  const int Q = a.C / 16, Qout = a.C / 8, Cout = 2 * a.C;
+  const int Q = a.C / 16, Cout = CG * (a.C / 4), Qout = Cout / 16;
   const int n0 = (int)((long long)blockIdx.y * a.n / slices);
   if (n0 >= a.n) return;
   const int n1 = (int)((long long)(blockIdx.y + 1) * a.n / slices);
@@ -343,19 +381,24 @@ __global__ __launch_bounds__(kGateThreads) void gate_pf_kernel(GateBlockArgs a, 
       const uint32_t b3 = (cur[2] >> sh) & 0xFF, b4 = (cur[3] >> sh) & 0xFF;
       const uint32_t i0 = (b1 & 15) | ((b2 & 15) << 4) | ((b3 & 15) << 8) | ((b4 & 15) << 12);
       const uint32_t i1 = (b1 >> 4) | ((b2 >> 4) << 4) | ((b3 >> 4) << 8) | ((b4 >> 4) << 12);
-      r = lds[i0] | ((uint32_t)lds[65536 + i1] << 8);
       const int oy = (t % chunks) * RPW + sub;
-      out_cp[(((size_t)n * Qout + j) * HO + oy) * WO + ox] = (uint16_t)r;
+      if constexpr (CG == 8) {
+        r = lds[i0] | ((uint32_t)lds[65536 + i1] << 8);
+        out_cp[(((size_t)n * Qout + j) * HO + oy) * WO + ox] = (uint16_t)r;
+      } else {
+        r = (lds[i0] & 15u) | (((uint32_t)lds[65536 + i1] & 15u) << 4);
+        ((uint8_t *)out_cp)[((((size_t)n * Qout + (j >> 1)) * HO + oy) * WO + ox) * 2 + (j & 1)] = (uint8_t)r;
+      }
     }
     uint32_t klo = 0, khi = 0;
-    BitBallots<0>::run(r, klo, khi);
-    if (lane < 16) {
+    BitBallots<0, 2 * CG>::run(r, klo, khi);
+    if (lane < 2 * CG) {
       const uint64_t m = ((uint64_t)khi << 32) | klo;
 #pragma unroll
       for (int s = 0; s < RPW; ++s) {
         const int oys = (t % chunks) * RPW + s;
         if (oys < HO)
-          out_rp[((size_t)n * Cout + 16 * j + lane) * HO + oys] = (m >> (s * LPR)) & ((1ull << LPR) - 1ull);
+          out_rp[((size_t)n * Cout + 2 * CG * j + lane) * HO + oys] = (m >> ((s * LPR) & 63)) & row_mask;
       }
     }
     }
@@ -458,7 +501,7 @@ int allow_big_lds(K kernel, size_t bytes) {
   return ensure_dynamic_lds((const void *)kernel, bytes);
 }
 
-template <int H, int HO>
+template <int H, int HO, int STRIDE = 2>
 int launch_stage1_t(const GateBlockArgs &a, hipStream_t s) {
   // 1 workgroup per CU (128 KiB of tables in LDS), and every workgroup pays ~2 us of table
   // staging: the whole launch is one round of the chip, 224 depthwise + 32 conv3 workgroups
@@ -466,18 +509,18 @@ int launch_stage1_t(const GateBlockArgs &a, hipStream_t s) {
   const int n_dw = (a.C / 16) * 2, n_pw = a.C / 16;
   const int sl_dw = slices_for(a.n, n_dw, 224), sl_pw = slices_for(a.n, n_pw, 32);
   const int dw_blocks = n_dw * sl_dw, pw_blocks = n_pw * sl_pw;
-  auto k = gate_stage1_kernel<4, 4, 2, 2, H, HO>;
+  auto k = gate_stage1_kernel<4, 4, STRIDE, 2, H, HO>;
   TT_TRY(allow_big_lds(k, kTableLds));
   hipLaunchKernelGGL(k, dim3(dw_blocks + pw_blocks), dim3(kGateThreads), kTableLds, s, a, n_dw, dw_blocks, sl_dw, sl_pw);
   TT_HIP(hipGetLastError());
   return TTNET_OK;
 }
 
-template <int HO>
+template <int HO, int CG = 8>
 int launch_pf_t(const GateBlockArgs &a, const uint8_t *t_cf, uint16_t *out_cp, uint64_t *out_rp, hipStream_t s) {
   const int units = a.C / 8;
   const int slices = slices_for(a.n, units, 256);
-  auto k = gate_pf_kernel<HO>;
+  auto k = gate_pf_kernel<HO, CG>;
   TT_TRY(allow_big_lds(k, kTableLds));
   hipLaunchKernelGGL(k, dim3(units, slices), dim3(kGateThreads), kTableLds, s, a, t_cf, out_cp, out_rp, slices);
   TT_HIP(hipGetLastError());
@@ -487,11 +530,20 @@ int launch_pf_t(const GateBlockArgs &a, const uint8_t *t_cf, uint16_t *out_cp, u
 }  // namespace
 
 int launch_gate_stage1(const GateBlockArgs &a, hipStream_t s) {
-  if (a.C % 16 || a.H != a.W || a.Ho != a.Wo || a.kh1 != 4 || a.kw1 != 4 || a.kh2 != 4 || a.kw2 != 4 || a.stride != 2 ||
-      a.pad != 2) {
+  if (a.C % 16 || a.H != a.W || a.Ho != a.Wo || a.kh1 != 4 || a.kw1 != 4 || a.kh2 != 4 || a.kw2 != 4 ||
+      (a.stride != 2 && a.stride != 1) || a.pad != 2) {
     set_error("gate_stage1: unsupported geometry C=%d %dx%d k=%dx%d", a.C, a.H, a.W, a.kh1, a.kw1);
     return TTNET_E_UNSUPPORTED;
   }
+  if (a.stride == 1) {                     // --layers 3/4 (TT_general_imagenet_v2_small.py:178-181)
+    if (a.H == 56 && a.Ho == 57) return launch_stage1_t<56, 57, 1>(a, s);
+    if (a.H == 29 && a.Ho == 30) return launch_stage1_t<29, 30, 1>(a, s);
+    set_error("gate_stage1: no stride-1 kernel for %dx%d -> %dx%d", a.H, a.W, a.Ho, a.Wo);
+    return TTNET_E_UNSUPPORTED;
+  }
+  if (a.H == 57 && a.Ho == 29) return launch_stage1_t<57, 29>(a, s);
+  if (a.H == 30 && a.Ho == 16) return launch_stage1_t<30, 16>(a, s);
+  if (a.H == 16 && a.Ho == 9) return launch_stage1_t<16, 9>(a, s);
   if (a.H == 56 && a.Ho == 29) return launch_stage1_t<56, 29>(a, s);
   if (a.H == 29 && a.Ho == 15) return launch_stage1_t<29, 15>(a, s);
   if (a.H == 15 && a.Ho == 8) return launch_stage1_t<15, 8>(a, s);
@@ -501,6 +553,18 @@ int launch_gate_stage1(const GateBlockArgs &a, hipStream_t s) {
 }
 
 int launch_gate_pf(const GateBlockArgs &a, const uint8_t *t_cf, uint16_t *out_cp, uint64_t *out_rp, hipStream_t s) {
+  if (a.cf_bits == 4) {
+    if (a.Ho == 30) return launch_pf_t<30, 4>(a, t_cf, out_cp, out_rp, s);
+    set_error("gate_pf: no 4-bit-group kernel for %dx%d", a.Ho, a.Wo);
+    return TTNET_E_UNSUPPORTED;
+  }
+  if (a.cf_bits != 8) {
+    set_error("gate_pf: %d output bits per convf group", a.cf_bits);
+    return TTNET_E_UNSUPPORTED;
+  }
+  if (a.Ho == 57) return launch_pf_t<57>(a, t_cf, out_cp, out_rp, s);
+  if (a.Ho == 30) return launch_pf_t<30>(a, t_cf, out_cp, out_rp, s);
+  if (a.Ho == 16) return launch_pf_t<16>(a, t_cf, out_cp, out_rp, s);
   if (a.Ho == 29) return launch_pf_t<29>(a, t_cf, out_cp, out_rp, s);
   if (a.Ho == 15) return launch_pf_t<15>(a, t_cf, out_cp, out_rp, s);
   if (a.Ho == 8) return launch_pf_t<8>(a, t_cf, out_cp, out_rp, s);

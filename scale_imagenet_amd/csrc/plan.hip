@@ -317,14 +317,20 @@ int build_geometry(ttnet_plan *pl) {
     set_error("p = nfilter*tfilter = %d: the stem kernel covers p <= 64 (and the table variants need p = 64)", p);
     return TTNET_E_UNSUPPORTED;
   }
-  std::vector<int> cfg;
-  switch (d.layers) {   // all stride 2 (:172-177)
-    case 0: cfg = {p, 2 * p}; break;
-    case 1: cfg = {p, 2 * p, 4 * p}; break;
-    case 2: cfg = {p, 2 * p, 4 * p, 8 * p}; break;
+  std::vector<int> cfg, strides;
+  switch (d.layers) {   // TT_general_imagenet_v2_small.py:172-181; a bare entry is a stride-1 block
+    case 0: cfg = {p, 2 * p}; strides = {2, 2}; break;
+    case 1: cfg = {p, 2 * p, 4 * p}; strides = {2, 2, 2}; break;
+    case 2: cfg = {p, 2 * p, 4 * p, 8 * p}; strides = {2, 2, 2, 2}; break;
+    case 3: cfg = {p, 2 * p, 4 * p, 8 * p}; strides = {1, 2, 2, 2}; break;
+    case 4: cfg = {p, 2 * p, 2 * p, 4 * p, 8 * p}; strides = {1, 2, 1, 2, 2}; break;
     default:
-      set_error("--layers %d (stride-1 blocks) is not supported yet", d.layers);
+      set_error("--layers %d: the reference defines 0..4", d.layers);
       return TTNET_E_UNSUPPORTED;
+  }
+  if (d.layers >= 3 && (pl->xs || pl->full)) {
+    set_error("--layers %d (stride-1 blocks) is built for the small variant only", d.layers);
+    return TTNET_E_UNSUPPORTED;
   }
   add_tensor(pl, "features.1.weight", {p, 3, 7, 7}, TTNET_F32, true);
   add_bn(pl, "features.2", p);
@@ -337,7 +343,9 @@ int build_geometry(ttnet_plan *pl) {
     const int out_planes = cfg[i];
     mh.last = (out_planes == cfg.back());
     mh.C = in_planes; mh.H = h; mh.W = w;
-    int ho = (h + 2 * pad - kh) / 2 + 1, wo = (w + 2 * pad - kw) / 2 + 1;
+    const int stride = strides[i];
+    mh.stride = stride;
+    int ho = (h + 2 * pad - kh) / stride + 1, wo = (w + 2 * pad - kw) / stride + 1;
     if (pl->full) {
       // models/TT_general_imagenet_v2.py:98-128: conv1 is (6,5), conv2 (5,6); at 29x29 they come
       // out 15x16 / 16x15 and are padded (bottom / right) to 16x16, out3/out4 by (0,2,0,2)
@@ -351,12 +359,12 @@ int build_geometry(ttnet_plan *pl) {
     } else {
     // branch padding keyed by the input width (:98-139): out3/out4 are floor(h/2) wide
     if (w == 56) mh.off34 = 1;                       // pad0 = ZeroPad2d((1,0,1,0))
-    else if (w == 29 || w == 15 || w == 8 || w == 16 || w == 30) mh.off34 = 0;   // pad2 = (0,1,0,1)
+    else if (w == 29 || w == 15 || w == 8 || w == 16 || w == 30 || w == 57 || w == 58) mh.off34 = 0;   // pad2 = (0,1,0,1)
     else {
       set_error("%s: no branch-padding rule for width %d", mh.name.c_str(), w);
       return TTNET_E_UNSUPPORTED;
     }
-    if (h / 2 + 1 != ho || w / 2 + 1 != wo || h != w) {
+    if (h / stride + 1 != ho || w / stride + 1 != wo || h != w) {
       set_error("%s: branch shapes do not line up (%dx%d -> %dx%d)", mh.name.c_str(), h, w, ho, wo);
       return TTNET_E_UNSUPPORTED;
     }
@@ -367,8 +375,8 @@ int build_geometry(ttnet_plan *pl) {
       return TTNET_E_INVALID;
     }
     const int kh1 = pl->full ? 6 : kh, kw1 = pl->full ? 5 : kw, kh2 = pl->full ? 5 : kh, kw2 = pl->full ? 6 : kw;
-    mh.c1.g = make_geom(mh.name + ".Block_conv1", in_planes, in_planes, kh1, kw1, 2, pad, in_planes, false);
-    mh.c2.g = make_geom(mh.name + ".Block_conv2", in_planes, in_planes, kh2, kw2, 2, pad, in_planes, false);
+    mh.c1.g = make_geom(mh.name + ".Block_conv1", in_planes, in_planes, kh1, kw1, stride, pad, in_planes, false);
+    mh.c2.g = make_geom(mh.name + ".Block_conv2", in_planes, in_planes, kh2, kw2, stride, pad, in_planes, false);
     mh.c3.g = make_geom(mh.name + ".Block_conv3", in_planes, in_planes, 1, 1, 1, 0, in_planes / gsize, false);
     const int cf_out = mh.last ? 4 * in_planes : 2 * out_planes;
     mh.cf.g = make_geom(mh.name + ".Block_convf", 4 * in_planes, cf_out, 1, 1, 1, 0, 4 * in_planes / gsize, mh.last);
@@ -612,6 +620,7 @@ GateBlockArgs gate_args(ttnet_plan *pl, size_t i, int n) {
   a.n = n; a.C = mh.C; a.H = mh.H; a.W = mh.W; a.Ho = mh.Ho; a.Wo = mh.Wo; a.off34 = mh.off34;
   a.kh1 = mh.c1.g.kh; a.kw1 = mh.c1.g.kw; a.kh2 = mh.c2.g.kh; a.kw2 = mh.c2.g.kw;
   a.stride = mh.c1.g.stride; a.pad = mh.c1.g.pad;
+  a.cf_bits = mh.cf.g.cout_g();
   a.x_rp = pl->x_rp[i]; a.x_cp = pl->x_cp[i];
   a.t_dw1 = (const uint8_t *)mh.c1.table; a.t_dw2 = (const uint8_t *)mh.c2.table;
   a.t_c3 = (const uint16_t *)mh.c3.table;

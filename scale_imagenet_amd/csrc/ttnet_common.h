@@ -150,6 +150,7 @@ struct GateBlockArgs {
   int Ho, Wo;            // branch output size after padding
   int off34;             // left/top zero padding of out3/out4 (1 at W=56, else 0)
   int kh1, kw1, kh2, kw2, stride, pad;
+  int cf_bits;           // output bits per Block_convf group (8; 4 when convf keeps the channel count)
   const uint64_t *x_rp;  // [n][C][H]
   const uint16_t *x_cp;  // [n][C/16][H][W]
   const uint8_t *t_dw1, *t_dw2;   // [C/16][2^n/32][16] dwords: 16 channels striped per dword
@@ -159,7 +160,7 @@ struct GateBlockArgs {
 // stage 1: Block_conv1, Block_conv2 (depthwise units) and Block_conv3 + both majority pools
 int launch_gate_stage1(const GateBlockArgs &a, hipStream_t s);
 // stage 2: convf of a non-last block: 4 branch tensors -> words [n][Cout/16][Ho][Wo] and rows
-// [n][Cout][Ho], Cout = 8 * (4C/16)
+// [n][Cout][Ho], Cout = cf_bits * (4C/16)
 int launch_gate_pf(const GateBlockArgs &a, const uint8_t *t_cf, uint16_t *out_cp, uint64_t *out_rp, hipStream_t s);
 // convf of the last block through the float table, AvgPool2d(2) fused; the features are
 // written pre-split for lin1: fragment-ordered fp16 planes [n/32][(g*PP+pp)][2][64][8]

@@ -101,8 +101,9 @@ _VARIANTS = {
 # Shape-keyed zero padding of the four branches before the concat
 # (TT_general_imagenet_v2_small.py:98-139).  Keyed by the block INPUT width; value is
 # (pad of out1, pad of out2, pad of out3/out4), each (left, right, top, bottom).
-# Only the stride-2 rows reachable at 224x224 / --layers 0..2 are listed; an unknown
-# width is an error here (the reference would fall through and fail in torch.cat).
+# Only the rows reachable at 224x224 / --layers 0..4 are listed; an unknown width is an error
+# here (the reference would fall through and fail in torch.cat).  Stride-1 blocks (--layers
+# 3/4) use the same width-keyed rows: out3 = conv3(x) and out4 = x keep the input size (:95-96).
 _Z = (0, 0, 0, 0)
 PAD_TABLE_SMALL: Dict[int, Tuple[Tuple[int, int, int, int], ...]] = {
     56: (_Z, _Z, (1, 0, 1, 0)),     # :107-109  pad0 = ZeroPad2d((1,0,1,0))
@@ -111,6 +112,8 @@ PAD_TABLE_SMALL: Dict[int, Tuple[Tuple[int, int, int, int], ...]] = {
     8: (_Z, _Z, (0, 1, 0, 1)),      # :126-128
     16: (_Z, _Z, (0, 1, 0, 1)),     # :120-122
     30: (_Z, _Z, (0, 1, 0, 1)),     # :137-139
+    57: (_Z, _Z, (0, 1, 0, 1)),     # :115-119
+    58: (_Z, _Z, (0, 1, 0, 1)),     # :134-136
 }
 PAD_TABLE_FULL: Dict[int, Tuple[Tuple[int, int, int, int], ...]] = {
     56: (_Z, _Z, (1, 0, 1, 0)),                              # v2.py:107-109
@@ -171,8 +174,8 @@ def make_spec(variant: str = "small", nfilter: int = 8, tfilter: int = 8, layers
         c3 = BlockTTSpec(f"{name}.Block_conv3", in_planes, in_planes, 1, 1, 1, 0, g3)
         cf_out = 4 * in_planes if last else 2 * out_planes
         cf = BlockTTSpec(f"{name}.Block_convf", 4 * in_planes, cf_out, 1, 1, 1, 0, gf, last=last)
-        if stride != 2:
-            raise NotImplementedError("stride-1 multi-head blocks (--layers 3/4) are not built yet")
+        if stride == 1 and variant != "small":
+            raise NotImplementedError("stride-1 multi-head blocks are built for the small variant only")
         tbl = pad_table(variant)
         if w not in tbl or h != w:
             raise ValueError(f"{name}: no branch-padding rule for input {h}x{w} "
@@ -182,7 +185,7 @@ def make_spec(variant: str = "small", nfilter: int = 8, tfilter: int = 8, layers
         h2, w2 = c2.out_hw(h, w)
         s1 = (h1 + p1[2] + p1[3], w1 + p1[0] + p1[1])
         s2 = (h2 + p2[2] + p2[3], w2 + p2[0] + p2[1])
-        s34 = (h // 2 + p34[2] + p34[3], w // 2 + p34[0] + p34[1])
+        s34 = (h // stride + p34[2] + p34[3], w // stride + p34[0] + p34[1])      # stride 1: out3 / out4 keep the input size
         if not (s1 == s2 == s34):
             raise ValueError(f"{name}: branch shapes differ after padding: {s1} {s2} {s34}")
         blocks.append(MultiHeadSpec(name, in_planes, out_planes, stride, last, c1, c2, c3, cf, (h, w), s1))

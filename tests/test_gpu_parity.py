@@ -484,11 +484,11 @@ def test_cabi_comm_single_rank(dev):
     lib.ttnet_comm_destroy(comm)
 
 
-@pytest.mark.parametrize("layers", [0, 2])
+@pytest.mark.parametrize("layers", [0, 2, 3, 4])
 def test_other_depths_against_the_oracle(dev, layers):
-    """--layers 0 / 2 (two and four stride-2 blocks, TT_general_imagenet_v2_small.py:172-177):
-    no golden capture exists for these depths, so the HIP path is checked against the pinned
-    oracle on the same synthetic weights: gate bits from the oracle's stem bits must be
+    """--layers 0 / 2 (two and four stride-2 blocks) and 3 / 4 (a stride-1 first block, and a second
+    one at 29x29; TT_general_imagenet_v2_small.py:172-181): the HIP path is checked against the
+    oracle (pinned to the reference for every depth) on the same synthetic weights: gate bits from the oracle's stem bits must be
     identical (tables are float64 on both sides), logits within 1e-5 of the exact head."""
     from argparse import Namespace
     from scale_imagenet_amd.spec import make_spec
@@ -512,6 +512,14 @@ def test_other_depths_against_the_oracle(dev, layers):
     assert y.shape == (3, 1000)
     scale = max(1.0, float(np.abs(ref).max()))
     assert np.abs(y - ref).max() <= 1e-5 * scale, (layers, np.abs(y - ref).max(), scale)
+    if layers >= 3:      # the reference's own logits for these depths (oracle/gen_golden.py depth)
+        from _util import GOLD
+        with np.load(os.path.join(GOLD, f"ref_small_l{layers}.npz")) as z:
+            want = z["logits"]
+        k = want.shape[0]
+        assert np.array_equal(y[:k].argmax(1), want.argmax(1))
+        assert np.abs(y[:k] - want).max() < 1e-2 * scale       # a near-tie flip moves logits a little, never far
+        print(f"--layers {layers}: |gpu - reference| {np.abs(y[:k] - want).max():.2e} on {k} images")
 
 
 def test_valexnet_config5(dev):

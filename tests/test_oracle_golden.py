@@ -123,3 +123,23 @@ def test_valexnet_oracles_reproduce_reference():
     yb, logits = OB.valexnet_from_stem_bits(taps["features.4"].numpy().astype(np.uint8), st, spec, luts)
     assert sha(OB.pack_rows(yb)) == j["stages"]["features.5"]["rows_sha256"]
     assert np.abs(logits - g["logits"]).max() < 2e-5
+
+
+@pytest.mark.parametrize("layers", [3, 4])
+def test_float_oracle_stride1_depths_match_reference(layers):
+    """--layers 3 / 4 (stride-1 blocks, TT_general_imagenet_v2_small.py:95-96, :178-181): the oracle
+    reproduces the logits and stage bits the imported reference produced (oracle/gen_golden.py depth)."""
+    import os
+    from _util import GOLD
+    from scale_imagenet_amd.spec import make_spec, state_dict_layout
+    with np.load(os.path.join(GOLD, f"ref_small_l{layers}.npz")) as z:
+        g = {k: z[k] for k in z.files}
+    spec = make_spec("small", 8, 8, layers)
+    assert len(state_dict_layout(spec)) == int(g["n_keys"])
+    st = synth.synth_state_dict(spec, calibrated=False)
+    n = int(g["n_images"])
+    taps = {}
+    y = OF.forward(torch.from_numpy(synth.synth_images(n)), OF.to_torch_state(st), spec, taps)
+    assert np.array_equal(y.numpy(), g["logits"])
+    for name, want in zip(g["stage_names"], g["stage_sha"]):
+        assert sha(OB.pack_rows(taps[str(name)].numpy().astype(np.uint8))) == str(want), name
