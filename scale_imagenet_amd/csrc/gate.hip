@@ -163,12 +163,81 @@ __device__ inline uint32_t dw_row_4x4s2(const uint64_t (&rows)[4], const uint32_
   return acc;
 }
 
+// Both depthwise branches at once.  Block_conv1 and Block_conv2 read the same input windows, so
+// the window index (the expensive part: four funnel shifts and four masked merges per column pair)
+// is formed once and looked up in both tables.  The LDS table set of such a unit is striped as
+// slot = 8 * branch + (channel & 7): the dwords of conv1 and conv2 for one index sit 32 bytes apart
+// and come with one ds_read2_b32.
+template <int P, bool HIGH_HALF>
+__device__ inline void dw_pair2(const uint32_t (&d)[4][3], const uint32_t *tab32_bytes, uint32_t c4, uint32_t &acc1,
+                                uint32_t &acc2) {
+  constexpr int SH = 2 * P, J = SH / 32, R = SH % 32;
+  uint32_t idx2;
+  {
+    const uint32_t a0 = R ? __builtin_amdgcn_alignbit(d[0][J + 1], d[0][J], R) : d[0][J];
+    const uint32_t a1 = R ? __builtin_amdgcn_alignbit(d[1][J + 1], d[1][J], R) : d[1][J];
+    const uint32_t a2 = R ? __builtin_amdgcn_alignbit(d[2][J + 1], d[2][J], R) : d[2][J];
+    const uint32_t a3 = R ? __builtin_amdgcn_alignbit(d[3][J + 1], d[3][J], R) : d[3][J];
+    idx2 = (a0 & 0x000F000Fu) | (a1 & 0x00F000F0u) | (a2 & 0x0F000F00u) | (a3 & 0xF000F000u);
+  }
+  const uint8_t *tb = (const uint8_t *)tab32_bytes;
+  {
+    const uint32_t *row = (const uint32_t *)(tb + (((idx2 & 0xFFE0u) << 1) | c4));
+    const uint32_t w1 = row[0], w2 = row[8];
+    acc1 |= ((w1 >> (idx2 & 31u)) & 1u) << P;
+    acc2 |= ((w2 >> (idx2 & 31u)) & 1u) << P;
+  }
+  if constexpr (HIGH_HALF) {
+    const uint32_t *row = (const uint32_t *)(tb + (((idx2 >> 15) & 0x1FFC0u) | c4));
+    const uint32_t w1 = row[0], w2 = row[8], sh = idx2 >> 16;
+    acc1 |= ((w1 >> (sh & 31u)) & 1u) << (P + 8);
+    acc2 |= ((w2 >> (sh & 31u)) & 1u) << (P + 8);
+  }
+}
+
+// 16x16 bit transpose across a 16-lane group, both 16-bit halves at once
+__device__ inline uint32_t transpose16(uint32_t acc, const DwLaneConst &k) {
+  constexpr int S[4] = {8, 4, 2, 1};
+  static_for<0, 4>([&](auto i) {
+    constexpr int I = decltype(i)::value;
+    const uint32_t partner = (uint32_t)__builtin_amdgcn_ds_swizzle((int)acc, 0x1F | (S[I] << 10));
+    const uint32_t moved = __builtin_amdgcn_alignbit(partner, partner, k.rot[I]);
+    acc = (acc & k.keep[I]) | (moved & ~k.keep[I]);
+  });
+  return acc;
+}
+
+// rows: the lane's four input rows.  Lane = (channel & 7, row slot); a 16-lane group is 8 channels x
+// two consecutive output rows.  Returns, for branch b, the transposed word of lane j = lane & 15:
+// byte 0 / 1 = the 8 channels of column j in the even / odd row of the group, bytes 2 / 3 the same
+// for column 16 + j.
+template <int WO>
+__device__ inline void dw_rows_4x4s2_both(const uint64_t (&rows)[4], const uint32_t *tab32, const DwLaneConst &k,
+                                          uint32_t &out1, uint32_t &out2) {
+  uint32_t d[4][3];
+#pragma unroll
+  for (int kh = 0; kh < 4; ++kh) {
+    const uint32_t lo = (uint32_t)rows[kh], hi = (uint32_t)(rows[kh] >> 32);
+    const int sh = 2 + 4 * kh;
+    d[kh][0] = lo << sh;
+    d[kh][1] = __builtin_amdgcn_alignbit(hi, lo, 32 - sh);
+    d[kh][2] = hi >> (32 - sh);
+  }
+  uint32_t acc1 = 0, acc2 = 0;
+  static_for<0, 8>([&](auto p) { dw_pair2<decltype(p)::value, (WO > 8)>(d, tab32, k.c4, acc1, acc2); });
+  if constexpr (WO > 16) static_for<16, 24>([&](auto p) { dw_pair2<decltype(p)::value, (WO > 24)>(d, tab32, k.c4, acc1, acc2); });
+  out1 = transpose16(acc1, k);
+  out2 = transpose16(acc2, k);
+}
+
 // ---- stage 1: depthwise Block_conv1/2 units and Block_conv3+majority units --------------------
-// 1-D grid: blocks [0, n_dw*slices_dw) are depthwise units (unit u = b % n_dw: q = u>>1,
-// branch = u&1; slice = b / n_dw) and are dispatched first; the remaining blocks are conv3
-// units (q = b' % n_pw, slice = b' / n_pw), short, and fill CUs as depthwise blocks retire.
-// dw: lane = (channel c = lane&15, row slot = lane>>4); each lane walks one output row of its
-// channel; the ballot of the wave is four channel words (4 rows x 16 channels) of one column.
+// 1-D grid: blocks [0, n_dw*slices_dw) are depthwise units (unit u = b % n_dw, slice = b / n_dw)
+// and are dispatched first; the remaining blocks are conv3 units (q = b' % n_pw, slice = b' / n_pw).
+// dw, 4x4 / stride 2 (the common case): unit = (group q = u>>1, half = u&1) = 8 channels x BOTH
+// branches; lane = (channel & 7, row slot); each lane walks one output row of its channel for
+// conv1 and conv2 with one window index per column pair (dw_pair2) and writes one byte (its 8
+// channels) of the output words.  Other geometries (stride 1): unit = (q, branch), lane =
+// (channel c = lane&15, row slot = lane>>4), output words by ballot (dw_row).
 template <int KH, int KW, int STRIDE, int PAD, int H, int HO>
 __global__ __launch_bounds__(kGateThreads) void gate_stage1_kernel(GateBlockArgs a, int n_dw, int dw_blocks, int slices_dw,
                                                                   int slices_pw) {
@@ -179,11 +248,69 @@ __global__ __launch_bounds__(kGateThreads) void gate_stage1_kernel(GateBlockArgs
 
   if ((int)blockIdx.x < dw_blocks) {
     const int unit = blockIdx.x % n_dw;
-    const int q = unit >> 1, branch = unit & 1;
     const int sl = blockIdx.x / n_dw;                   // batch slices of (almost) equal size
     const int n0 = (int)((long long)sl * a.n / slices_dw);
     if (n0 >= a.n) return;
     const int n1 = (int)((long long)(sl + 1) * a.n / slices_dw);
+    if constexpr (KH == 4 && KW == 4 && STRIDE == 2 && PAD == 2 && WO <= 32) {
+      // unit = (group q, half h): 8 channels, BOTH branches (see dw_pair2)
+      const int q = unit >> 1, half = unit & 1;
+      {   // LDS block i (16 bytes = 4 slots) of striped row w = i >> 2: slots 0-7 from conv1's table, 8-15 from conv2's
+        const uint8_t *t1 = a.t_dw1 + (size_t)q * kTableLds + 32 * half, *t2 = a.t_dw2 + (size_t)q * kTableLds + 32 * half;
+        for (int chunk = wave; chunk < kTableLds / 1024; chunk += nwaves) {
+          const int i = chunk * 64 + lane, w = i >> 2, part = i & 3;
+          const uint8_t *src = (part < 2 ? t1 : t2) + (size_t)w * 64 + 16 * (part & 1);
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                           (__attribute__((address_space(3))) void *)(lds + chunk * 1024), 16, 0, 0);
+        }
+      }
+      const uint32_t ch8 = lane & 7, slot = lane >> 3;
+      constexpr int rows8 = (HO + 7) / 8;
+      const int tasks = (n1 - n0) * rows8;
+      auto load_rows = [&](int t, uint64_t (&r)[KH]) {
+        const int n = n0 + t / rows8, oy = (t % rows8) * 8 + (int)slot;
+#pragma unroll
+        for (int kh = 0; kh < KH; ++kh) {
+          const int iy = oy * STRIDE - PAD + kh;
+          r[kh] = (t < tasks && oy < HO && iy >= 0 && iy < H) ? a.x_rp[((size_t)n * a.C + 16 * q + 8 * half + ch8) * H + iy] : 0ull;
+        }
+      };
+      uint64_t cur[KH], nxt[KH];
+      load_rows(wave, cur);
+      DwLaneConst lk = dw_lane_const(lane);
+      lk.c4 = ch8 << 2;
+      wait_lds_stage();
+      const uint32_t *tab32 = (const uint32_t *)lds;
+      const int col = lane & 15, rsub = 2 * (lane >> 4);
+      for (int t = wave; t < tasks; t += nwaves) {
+        load_rows(t + nwaves, nxt);                       // prefetch the next task's rows
+        const int n = n0 + t / rows8, row = (t % rows8) * 8 + rsub;
+        uint32_t w1, w2;
+        dw_rows_4x4s2_both<WO>(cur, tab32, lk, w1, w2);
+        // lane j = column j (and 16 + j) of rows `row`, `row + 1`: one byte (this unit's 8 channels) of each word
+        const size_t at = ((((size_t)n * Q + q) * HO + row) * WO + col) * 2 + half;
+        uint8_t *d1 = (uint8_t *)a.o1 + at, *d2 = (uint8_t *)a.o2 + at;
+        if (row < HO && col < WO) {
+          d1[0] = (uint8_t)w1;
+          d2[0] = (uint8_t)w2;
+          if (row + 1 < HO) {
+            d1[2 * WO] = (uint8_t)(w1 >> 8);
+            d2[2 * WO] = (uint8_t)(w2 >> 8);
+          }
+          if (16 + col < WO) {
+            d1[32] = (uint8_t)(w1 >> 16);
+            d2[32] = (uint8_t)(w2 >> 16);
+            if (row + 1 < HO) {
+              d1[2 * WO + 32] = (uint8_t)(w1 >> 24);
+              d2[2 * WO + 32] = (uint8_t)(w2 >> 24);
+            }
+          }
+        }
+#pragma unroll
+        for (int kh = 0; kh < KH; ++kh) cur[kh] = nxt[kh];
+      }
+    } else {
+    const int q = unit >> 1, branch = unit & 1;
     const uint8_t *tab = (branch ? a.t_dw2 : a.t_dw1) + (size_t)q * kTableLds;
     uint16_t *out = branch ? a.o2 : a.o1;
     stage_lds_async(lds, tab, kTableLds);
@@ -201,40 +328,31 @@ __global__ __launch_bounds__(kGateThreads) void gate_stage1_kernel(GateBlockArgs
     };
     uint64_t cur[KH], nxt[KH];
     load_rows(wave, cur);
-    [[maybe_unused]] const DwLaneConst lk = dw_lane_const(lane);
     wait_lds_stage();
     const uint32_t *tab32 = (const uint32_t *)lds;
     for (int t = wave; t < tasks; t += nwaves) {
       load_rows(t + nwaves, nxt);                       // prefetch the next task's rows
       const int n = n0 + t / rows4, oyb = (t % rows4) * 4;
       const bool valid = oyb + (int)slot < HO;
-      if constexpr (KH == 4 && KW == 4 && STRIDE == 2 && PAD == 2 && WO <= 32) {
-        const uint32_t words = dw_row_4x4s2<WO>(cur, tab32, lk);
-        if (valid) {
-          uint16_t *dst = out + (((size_t)n * Q + q) * HO + oyb + slot) * WO;
-          if (c < WO) dst[c] = (uint16_t)words;
-          if (16 + c < WO) dst[16 + c] = (uint16_t)(words >> 16);
-        }
-      } else {
-        const uint64_t vmask = __ballot(valid);
-        uint32_t lo[KH], hi[KH];
+      const uint64_t vmask = __ballot(valid);
+      uint32_t lo[KH], hi[KH];
 #pragma unroll
-        for (int kh = 0; kh < KH; ++kh) {
-          const uint64_t rp = cur[kh] << PAD;
-          lo[kh] = (uint32_t)rp;
-          hi[kh] = (uint32_t)(rp >> 32);
-        }
-        uint32_t keep_lo = 0, keep_hi = 0;
-        dw_row<KH, KW, STRIDE, WO>(lo, hi, tab32, c, keep_lo, keep_hi);
-        if (lane < WO) {
-          const uint64_t keep = (((uint64_t)keep_hi << 32) | keep_lo) & vmask;   // rows past HO: no bits
+      for (int kh = 0; kh < KH; ++kh) {
+        const uint64_t rp = cur[kh] << PAD;
+        lo[kh] = (uint32_t)rp;
+        hi[kh] = (uint32_t)(rp >> 32);
+      }
+      uint32_t keep_lo = 0, keep_hi = 0;
+      dw_row<KH, KW, STRIDE, WO>(lo, hi, tab32, c, keep_lo, keep_hi);
+      if (lane < WO) {
+        const uint64_t keep = (((uint64_t)keep_hi << 32) | keep_lo) & vmask;   // rows past HO: no bits
 #pragma unroll
-          for (int s = 0; s < 4; ++s)
-            if (oyb + s < HO) out[(((size_t)n * Q + q) * HO + oyb + s) * WO + lane] = (uint16_t)(keep >> (16 * s));
-        }
+        for (int s = 0; s < 4; ++s)
+          if (oyb + s < HO) out[(((size_t)n * Q + q) * HO + oyb + s) * WO + lane] = (uint16_t)(keep >> (16 * s));
       }
 #pragma unroll
       for (int kh = 0; kh < KH; ++kh) cur[kh] = nxt[kh];
+    }
     }
   } else {
     // Block_conv3 (16 -> 16 bits per pixel and group) + majority pools of conv3(x) and of x
@@ -504,10 +622,10 @@ int allow_big_lds(K kernel, size_t bytes) {
 template <int H, int HO, int STRIDE = 2>
 int launch_stage1_t(const GateBlockArgs &a, hipStream_t s) {
   // 1 workgroup per CU (128 KiB of tables in LDS), and every workgroup pays ~2 us of table
-  // staging: the whole launch is one round of the chip, 224 depthwise + 32 conv3 workgroups
+  // staging: the whole launch is one round of the chip, 208 depthwise + 48 conv3 workgroups
   // (measured best split at B = 256; a second round of conv3 blocks cost 3-5 us per launch).
   const int n_dw = (a.C / 16) * 2, n_pw = a.C / 16;
-  const int sl_dw = slices_for(a.n, n_dw, 224), sl_pw = slices_for(a.n, n_pw, 32);
+  const int sl_dw = slices_for(a.n, n_dw, 208), sl_pw = slices_for(a.n, n_pw, 48);
   const int dw_blocks = n_dw * sl_dw, pw_blocks = n_pw * sl_pw;
   auto k = gate_stage1_kernel<4, 4, STRIDE, 2, H, HO>;
   TT_TRY(allow_big_lds(k, kTableLds));
