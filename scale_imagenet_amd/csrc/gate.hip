@@ -464,6 +464,7 @@ __global__ __launch_bounds__(kGateThreads) void gate_pf_kernel(GateBlockArgs a, 
   const int wq = j >> 1, sh = 8 * (j & 1);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = kGateThreads / 64;
   const int sub = lane / LPR, ox = lane % LPR;
+  const DwLaneConst lk = dw_lane_const(lane);
   const int tasks = (n1 - n0) * chunks;
   auto load_words = [&](int t, uint32_t (&b)[4], size_t &pix, bool &valid) {
     const int n = n0 + t / chunks, oy = (t % chunks) * RPW + sub;
@@ -508,16 +509,26 @@ __global__ __launch_bounds__(kGateThreads) void gate_pf_kernel(GateBlockArgs a, 
         ((uint8_t *)out_cp)[((((size_t)n * Qout + (j >> 1)) * HO + oy) * WO + ox) * 2 + (j & 1)] = (uint8_t)r;
       }
     }
-    uint32_t klo = 0, khi = 0;
-    BitBallots<0, 2 * CG>::run(r, klo, khi);
-    if (lane < 2 * CG) {
-      const uint64_t m = ((uint64_t)khi << 32) | klo;
-#pragma unroll
-      for (int s = 0; s < RPW; ++s) {
-        const int oys = (t % chunks) * RPW + s;
-        if (oys < HO)
-          out_rp[((size_t)n * Cout + 2 * CG * j + lane) * HO + oys] = (m >> ((s * LPR) & 63)) & row_mask;
-      }
+    // rows of the next block's row-packed input: transpose the (pixel lane) x (channel bit) words of
+    // every 16-lane group in registers, then lane j < 2*CG holds channel j's bits of the group's 16
+    // pixels; the pieces of a row's groups are joined across lanes.  (16 ballots + 32 v_writelane
+    // per task before: four times the instructions.)
+    const uint32_t piece = transpose16(r, lk) & 0xFFFFu;
+    uint64_t rowbits;
+    if constexpr (LPR == 16) {
+      rowbits = piece;
+    } else if constexpr (LPR == 32) {
+      const uint32_t other = (uint32_t)__shfl_xor((int)piece, 16);
+      rowbits = piece | (other << 16);                   // used by the lanes with (lane & 16) == 0
+    } else {
+      const int j = lane & 15;
+      const uint32_t p1 = (uint32_t)__shfl((int)piece, j + 16), p2 = (uint32_t)__shfl((int)piece, j + 32),
+                     p3 = (uint32_t)__shfl((int)piece, j + 48);
+      rowbits = (uint64_t)(piece | (p1 << 16)) | ((uint64_t)(p2 | (p3 << 16)) << 32);   // lanes 0-15
+    }
+    if ((lane & (LPR - 1)) < 2 * CG) {
+      const int oy = (t % chunks) * RPW + sub;
+      if (oy < HO) out_rp[((size_t)n * Cout + 2 * CG * j + (lane & 15)) * HO + oy] = rowbits;
     }
     }
   }
