@@ -244,7 +244,9 @@ __global__ __launch_bounds__(kGateThreads) void gate_stage1_kernel(GateBlockArgs
   extern __shared__ __align__(16) uint8_t lds[];
   constexpr int W = H, WO = HO;
   const int Q = a.C / 16;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = kGateThreads / 64;
+  // (the wave index is forced into an SGPR: everything derived from it -- task, image, row group --
+  // is then scalar arithmetic instead of per-lane VALU work)
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nwaves = kGateThreads / 64;
 
   if ((int)blockIdx.x < dw_blocks) {
     const int unit = blockIdx.x % n_dw;
@@ -462,16 +464,18 @@ __global__ __launch_bounds__(kGateThreads) void gate_pf_kernel(GateBlockArgs a, 
   const int n1 = (int)((long long)(blockIdx.y + 1) * a.n / slices);
   stage_lds_async(lds, t_cf + (size_t)(2 * j) * 65536, kTableLds);
   const int wq = j >> 1, sh = 8 * (j & 1);
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = kGateThreads / 64;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nwaves = kGateThreads / 64;
   const int sub = lane / LPR, ox = lane % LPR;
+  const int lane_off = sub * WO + ox;                   // the lane's pixel inside a chunk of RPW rows
   const DwLaneConst lk = dw_lane_const(lane);
   const int tasks = (n1 - n0) * chunks;
   auto load_words = [&](int t, uint32_t (&b)[4], size_t &pix, bool &valid) {
-    const int n = n0 + t / chunks, oy = (t % chunks) * RPW + sub;
-    valid = t < tasks && oy < HO && ox < WO;
-    pix = (((size_t)n * Q + wq) * HO + oy) * WO + ox;
-    b[0] = valid ? a.o1[pix] : 0; b[1] = valid ? a.o2[pix] : 0;
-    b[2] = valid ? a.o3[pix] : 0; b[3] = valid ? a.o4[pix] : 0;
+    const int n = n0 + t / chunks, oyb = (t % chunks) * RPW;       // wave-uniform
+    valid = t < tasks && oyb + sub < HO && ox < WO;
+    const size_t base = (((size_t)n * Q + wq) * HO + oyb) * WO;     // uniform part of the address
+    pix = base + lane_off;
+    b[0] = valid ? (a.o1 + base)[lane_off] : 0; b[1] = valid ? (a.o2 + base)[lane_off] : 0;
+    b[2] = valid ? (a.o3 + base)[lane_off] : 0; b[3] = valid ? (a.o4 + base)[lane_off] : 0;
   };
   // The per-task work (two lookups, 16 ballots) is shorter than a global-load round trip, so
   // the four input words are fetched PF tasks ahead (a register ring; the loop is unrolled by PF
@@ -500,13 +504,13 @@ __global__ __launch_bounds__(kGateThreads) void gate_pf_kernel(GateBlockArgs a, 
       const uint32_t b3 = (cur[2] >> sh) & 0xFF, b4 = (cur[3] >> sh) & 0xFF;
       const uint32_t i0 = (b1 & 15) | ((b2 & 15) << 4) | ((b3 & 15) << 8) | ((b4 & 15) << 12);
       const uint32_t i1 = (b1 >> 4) | ((b2 >> 4) << 4) | ((b3 >> 4) << 8) | ((b4 >> 4) << 12);
-      const int oy = (t % chunks) * RPW + sub;
+      const int oyb = (t % chunks) * RPW;
       if constexpr (CG == 8) {
         r = lds[i0] | ((uint32_t)lds[65536 + i1] << 8);
-        out_cp[(((size_t)n * Qout + j) * HO + oy) * WO + ox] = (uint16_t)r;
+        (out_cp + (((size_t)n * Qout + j) * HO + oyb) * WO)[lane_off] = (uint16_t)r;
       } else {
         r = (lds[i0] & 15u) | (((uint32_t)lds[65536 + i1] & 15u) << 4);
-        ((uint8_t *)out_cp)[((((size_t)n * Qout + (j >> 1)) * HO + oy) * WO + ox) * 2 + (j & 1)] = (uint8_t)r;
+        ((uint8_t *)out_cp + ((((size_t)n * Qout + (j >> 1)) * HO + oyb) * WO) * 2 + (j & 1))[2 * lane_off] = (uint8_t)r;
       }
     }
     // rows of the next block's row-packed input: transpose the (pixel lane) x (channel bit) words of
