@@ -13,8 +13,8 @@ LABELS = [  # (substring of the kernel name, bench.py label, wide-stream correct
     ("stem_pc_kernel", "stem", True), ("gate_last", "gate_last", True), ("gemm_f16x2_kernel", "head.lin1", True),
     ("lin2_f16x2_kernel", "head.lin2", True), ("head_mid_kernel", "head.bn_poly", False),
     ("gate_stage1_kernel<4, 4, 2, 2, 56, 29>", "gate_stage1.f4", False), ("gate_stage1_kernel<4, 4, 2, 2, 29, 15>", "gate_stage1.f5", False),
-    ("gate_stage1_kernel<4, 4, 2, 2, 15, 8>", "gate_stage1.f6", False), ("gate_pf_kernel<29>", "gate_pf.f4", False),
-    ("gate_pf_kernel<15>", "gate_pf.f5", False),
+    ("gate_stage1_kernel<4, 4, 2, 2, 15, 8>", "gate_stage1.f6", False), ("gate_pf_kernel<29, 8>", "gate_pf.f4", False),
+    ("gate_pf_kernel<15, 8>", "gate_pf.f5", False),
 ]
 
 def per_launch(d, counter, batch_grid_hint=None):
