@@ -93,26 +93,6 @@ __device__ inline void dw_row(const uint32_t (&lo)[KH], const uint32_t (&hi)[KH]
 // Each lane accumulates its own output row (bit x = column x); the 16 lanes of a channel
 // group then transpose their 16x16 bit blocks in registers (4 butterfly stages, both
 // halves at once) so that lane j holds the channel words of columns j and 16+j.
-struct DwLaneConst {
-  uint32_t c4;          // byte offset of this lane's channel inside a striped table row
-  uint32_t rot[4];      // funnel-rotate amount of butterfly stage s = 8,4,2,1
-  uint32_t keep[4];     // bits this lane keeps in stage s
-};
-
-__device__ inline DwLaneConst dw_lane_const(uint32_t lane) {
-  DwLaneConst k;
-  k.c4 = (lane & 15) << 2;
-  constexpr uint32_t M[4] = {0x00FF00FFu, 0x0F0F0F0Fu, 0x33333333u, 0x55555555u};   // bit positions with (pos & s) == 0
-  constexpr uint32_t S[4] = {8, 4, 2, 1};
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const bool low = (lane & S[i]) == 0;
-    k.rot[i] = low ? 32 - S[i] : S[i];          // low lane takes partner << s, high lane partner >> s
-    k.keep[i] = low ? M[i] : ~M[i];
-  }
-  return k;
-}
-
 template <int P, bool HIGH_HALF>
 __device__ inline void dw_pair(const uint32_t (&d)[4][3], const uint32_t *tab32_bytes, uint32_t c4, uint32_t &acc) {
   // shift of the pair base column P: 2P bits; funnel over dwords (j, j+1)
@@ -193,18 +173,6 @@ __device__ inline void dw_pair2(const uint32_t (&d)[4][3], const uint32_t *tab32
     acc1 |= ((w1 >> (sh & 31u)) & 1u) << (P + 8);
     acc2 |= ((w2 >> (sh & 31u)) & 1u) << (P + 8);
   }
-}
-
-// 16x16 bit transpose across a 16-lane group, both 16-bit halves at once
-__device__ inline uint32_t transpose16(uint32_t acc, const DwLaneConst &k) {
-  constexpr int S[4] = {8, 4, 2, 1};
-  static_for<0, 4>([&](auto i) {
-    constexpr int I = decltype(i)::value;
-    const uint32_t partner = (uint32_t)__builtin_amdgcn_ds_swizzle((int)acc, 0x1F | (S[I] << 10));
-    const uint32_t moved = __builtin_amdgcn_alignbit(partner, partner, k.rot[I]);
-    acc = (acc & k.keep[I]) | (moved & ~k.keep[I]);
-  });
-  return acc;
 }
 
 // rows: the lane's four input rows.  Lane = (channel & 7, row slot); a 16-lane group is 8 channels x
@@ -429,18 +397,6 @@ __global__ __launch_bounds__(kGateThreads) void gate_stage1_kernel(GateBlockArgs
   }
 }
 
-// lane K of (klo,khi) := ballot of bit K of r, for K = 0..15
-template <int K, int NB = 16>
-struct BitBallots {
-  __device__ static inline void run(uint32_t r, uint32_t &klo, uint32_t &khi) {
-    if constexpr (K < NB) {
-      const uint64_t m = __ballot((r >> K) & 1u);
-      writelane64<K>(klo, khi, m);
-      BitBallots<K + 1, NB>::run(r, klo, khi);
-    }
-  }
-};
-
 // ---- stage 2: Block_convf of a binarised block ----------------------------------------------
 // The reference interleaves to channel 4c+branch (:144-147) and groups 16 of those: group g
 // reads channels 4g..4g+3 of each branch.  Internal index = nib(out1) | nib(out2)<<4 |
@@ -456,7 +412,6 @@ __global__ __launch_bounds__(kGateThreads) void gate_pf_kernel(GateBlockArgs a, 
   extern __shared__ __align__(16) uint8_t lds[];
   constexpr int WO = HO;
   constexpr int LPR = WO <= 16 ? 16 : (WO <= 32 ? 32 : 64), RPW = 64 / LPR, chunks = (HO + RPW - 1) / RPW;
-  constexpr uint64_t row_mask = LPR == 64 ? ~0ull : ((1ull << (LPR & 63)) - 1ull);
   const int j = blockIdx.x;              // output word; groups 2j, 2j+1
   const int Q = a.C / 16, Cout = CG * (a.C / 4), Qout = Cout / 16;
   const int n0 = (int)((long long)blockIdx.y * a.n / slices);

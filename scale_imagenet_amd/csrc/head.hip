@@ -217,7 +217,7 @@ __global__ void head_mid_kernel(const float *__restrict__ part, int splits, cons
 // workgroup (256 workgroups at M = 256, N = 1000: the kernel is bound by how fast one CU can pull
 // its 2 x 126 KiB of fragments out of L2, so the tiles are small and spread over all CUs), K
 // split over the 8 waves, partial tiles summed through LDS in wave order, bias fused.
-constexpr int L2_WAVES = 8, L2_STAGES = 4, L2_LDS = L2_WAVES * 16 * 64 * 4;
+constexpr int L2_WAVES = 8, L2_STAGES = 4;
 __global__ __launch_bounds__(64 * L2_WAVES) void lin2_f16x2_kernel(const uint4 *__restrict__ A, const uint4 *__restrict__ B,
                                                                    const float *__restrict__ bias, float inv,
                                                                    float *__restrict__ out, int M, int N, int KS) {

@@ -962,7 +962,7 @@ int forward_eager(ttnet_plan *pl, const void *x_dev, bool u8, int64_t n, float *
 // hipGraph captured on a private stream.  Only two pointers change between calls: the input
 // (argument 0 of the first kernel) and the logits (argument 4 of lin2, the last kernel); they
 // are patched into the instantiated graph when they differ from the previous call.
-constexpr int kFirstKernelArgs = 7, kLastKernelArgs = 8, kLastKernelOutArg = 4;   // (first: the leading 7 of stem_pc_kernel's 8)
+constexpr int kLastKernelArgs = 8, kLastKernelOutArg = 4;
 
 void drop_graph(ttnet_plan::GraphEntry &e) {
   if (e.exec) (void)hipGraphExecDestroy(e.exec);

@@ -59,28 +59,6 @@ constexpr int CONS_WAVES = 8, PROD_WAVES = 4, STEM_THREADS = 64 * (CONS_WAVES + 
 constexpr int UNITS = NT * 2;          // (N-tile, M-tile) pairs of one item: 28
 constexpr int UPW = (UNITS + CONS_WAVES - 1) / CONS_WAVES;   // units per consumer wave: 4 (waves 4-7: 3)
 
-// Four ballots (accumulator registers R0 .. R0+3) at once: lane R0+i of (klo,khi) := ballot i, and
-// the ballots' own lane bits are shifted into cw, highest register first (cw = cw*2 + bit: the
-// carry-in of v_addc is the ballot).  One s_nop covers the VALU -> SGPR -> VALU wait states that
-// hipcc does not insert inside an asm statement.
-template <int R0>
-__device__ inline void ballots4(uint32_t &klo, uint32_t &khi, uint32_t &cw, uint64_t m0, uint64_t m1, uint64_t m2, uint64_t m3) {
-  asm("s_nop 1\n\t"
-      "v_writelane_b32 %0, %3, %15\n\tv_writelane_b32 %1, %4, %15\n\t"
-      "v_writelane_b32 %0, %5, %16\n\tv_writelane_b32 %1, %6, %16\n\t"
-      "v_writelane_b32 %0, %7, %17\n\tv_writelane_b32 %1, %8, %17\n\t"
-      "v_writelane_b32 %0, %9, %18\n\tv_writelane_b32 %1, %10, %18\n\t"
-      "v_addc_co_u32 %2, vcc, %2, %2, %14\n\t"
-      "v_addc_co_u32 %2, vcc, %2, %2, %13\n\t"
-      "v_addc_co_u32 %2, vcc, %2, %2, %12\n\t"
-      "v_addc_co_u32 %2, vcc, %2, %2, %11"
-      : "+v"(klo), "+v"(khi), "+v"(cw)
-      : "s"((uint32_t)m0), "s"((uint32_t)(m0 >> 32)), "s"((uint32_t)m1), "s"((uint32_t)(m1 >> 32)), "s"((uint32_t)m2),
-        "s"((uint32_t)(m2 >> 32)), "s"((uint32_t)m3), "s"((uint32_t)(m3 >> 32)), "s"(m0), "s"(m1), "s"(m2), "s"(m3), "n"(R0),
-        "n"(R0 + 1), "n"(R0 + 2), "n"(R0 + 3)
-      : "vcc");
-}
-
 // Persistent producer / consumer kernel.  One workgroup per CU walks items (image, block of SR
 // output rows).  Producer waves stream the raw float32 rows from HBM, pool them and write the
 // two fp16 planes of the NEXT item's tile into the other half of an LDS double buffer;
@@ -88,12 +66,13 @@ __device__ inline void ballots4(uint32_t &klo, uint32_t &khi, uint32_t &cw, uint
 // barrier per item.  Consumer wave w owns units w, w+8, ...: all of one M-tile (u & 1 = w & 1), so
 // a wave needs only that M-tile's weight fragments; waves w and w+4 share a SIMD and carry 4 + 3
 // units.  BatchNorm is folded: its scale into the weights (host), its shift into the initial
-// value of the accumulators, so the epilogue is the sign test alone.
+// value of the accumulators, so the epilogue is the sign bit alone.
 //
 // Every vector instruction counts here (MFMA and VALU time add up on a SIMD): wave-uniform
 // indices are forced into SGPRs, border handling is a clamp of the load address plus a 0/4
-// multiplier instead of per-element selects, and everything that does not depend on the item is
-// computed once.
+// multiplier instead of per-element selects, sign bits are collected by funnel shifts and turned
+// into row words by an in-register bit transpose (no ballots), and everything that does not
+// depend on the item is computed once.
 //
 // U8 = true: the input is the decoder's uint8 HWC image and the last two steps of
 // the input pipeline, ToTensor (/255) and Normalize(mean, std) (utils/preprocess.py:104-108),
@@ -273,6 +252,7 @@ __global__ __launch_bounds__(STEM_THREADS) void stem_pc_kernel(const void *__res
 
   // ---- consumer side -----------------------------------------------------------------------
   const int h = lane >> 5, col = lane & 31;
+  const DwLaneConst tk = dw_lane_const(lane);
   const int m = wave & 1;                                // this wave's M-tile (consumers only)
   // per unit, independent of the item: dword offset of the lane's pixel in the tile, and its
   // offset in a channel-word plane
@@ -335,31 +315,36 @@ __global__ __launch_bounds__(STEM_THREADS) void stem_pc_kernel(const void *__res
       }
     }
     // epilogue: sign + pack.  C/D layout of the 32x32 MFMA: column = lane&31 (pixel),
-    // row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) (channel within the M-tile).  The ballot of
-    // register r is the row-word piece of two channels (lanes 0-31 / 32-63) over 32 pixels; the
-    // lane's own bits, collected over the registers, are its pixel's channel-word nibbles.
+    // row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) (channel within the M-tile).  A lane collects the
+    // sign bits of its 16 registers (one funnel shift each: w = w<<1 | sign): that word is its
+    // pixel's share of the channel words; transposed across each 16-lane group it becomes, in lane
+    // j, register j's bits over the group's 16 pixels, i.e. the row-word pieces.  (A result of
+    // exactly -0.0 would count as negative here and as >= 0 in the reference: |pre| = 0 lies in
+    // the near-tie band either way.)
 #pragma unroll
     for (int i = 0; i < UPW; ++i) {
       const int u = wave + CONS_WAVES * i;
       if (u >= UNITS) continue;
       const int t = u >> 1;
-      uint32_t klo = 0, khi = 0;             // lane r keeps the ballot of accumulator register r
-      uint32_t cw0 = 0, cw1 = 0;             // bit (r&3) + 4*((r>>2)&1) of cw0 (r < 8) / cw1 (r >= 8)
-      auto bal = [&](int r) { return __ballot(acc[i][r] >= 0.0f); };
-      ballots4<12>(klo, khi, cw1, bal(12), bal(13), bal(14), bal(15));
-      ballots4<8>(klo, khi, cw1, bal(8), bal(9), bal(10), bal(11));
-      ballots4<4>(klo, khi, cw0, bal(4), bal(5), bal(6), bal(7));
-      ballots4<0>(klo, khi, cw0, bal(0), bal(1), bal(2), bal(3));
+      uint32_t neg = 0;                      // bit r = sign bit of register r
+      static_for<0, 16>([&](auto rr) {
+        constexpr int r = 15 - decltype(rr)::value;
+        neg = __builtin_amdgcn_alignbit(neg, __float_as_uint(acc[i][r]), 31);
+      });
+      const uint32_t bits = ~neg & 0xFFFFu;  // bit r = (acc[r] >= 0)
       // channel word bit of register r: (r&3) + 8*((r>>2)&1) + 4*h within the 16-channel group r>>3
+      const uint32_t cw0 = bits & 0xFFu, cw1 = bits >> 8;
       uint32_t pw = ((cw0 & 15u) | ((cw0 & 0xF0u) << 4)) | (((cw1 & 15u) | ((cw1 & 0xF0u) << 4)) << 16);
       pw <<= 4 * h;
       pw |= (uint32_t)__shfl_xor((int)pw, 32);
       const int q = 2 * m + h;               // half-wave 0 stores group 2m, half-wave 1 group 2m+1
       if (cp) cp[((size_t)n * 4 + q) * (56 * 56) + oy0 * 56 + cpoff[i]] = (uint16_t)(h ? (pw >> 16) : pw);
-      if (lane < 16) {                        // lanes 0-31 of the ballot: channel chl, lanes 32-63: chl + 4
-        const int chl = m * 32 + (lane & 3) + 8 * (lane >> 2);
-        st[chl][t] = klo;
-        st[chl + 4][t] = khi;
+      // row-word pieces: lane j of a 16-lane group = register j over the group's 16 pixels
+      const uint32_t piece = transpose16(bits, tk) & 0xFFFFu;
+      const uint32_t other = (uint32_t)__shfl_xor((int)piece, 16);
+      if ((lane & 16) == 0) {                // lanes 0-15: channels of half 0, lanes 32-47: half 1 (+4)
+        const int j = lane & 15;
+        st[m * 32 + (j & 3) + 8 * (j >> 2) + 4 * h][t] = piece | (other << 16);
       }
     }
   };

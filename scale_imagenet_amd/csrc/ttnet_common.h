@@ -76,6 +76,43 @@ __device__ inline void static_for(F &&f) {
     static_for<I + 1, N>(f);
   }
 }
+
+// ---- 16x16 bit-matrix transpose across a 16-lane group (gate.hip, stem.hip) -----------------
+// Four butterfly stages (lane distance 8, 4, 2, 1): a lane exchanges words with its partner
+// (ds_swizzle), funnel-rotates the partner's word and keeps its own bits at the positions
+// selected by the stage mask.  Both 16-bit halves of the register are transposed at once.
+struct DwLaneConst {
+  uint32_t c4;          // byte offset of this lane's channel inside a striped table row
+  uint32_t rot[4];      // funnel-rotate amount of butterfly stage s = 8,4,2,1
+  uint32_t keep[4];     // bits this lane keeps in stage s
+};
+
+__device__ inline DwLaneConst dw_lane_const(uint32_t lane) {
+  DwLaneConst k;
+  k.c4 = (lane & 15) << 2;
+  constexpr uint32_t M[4] = {0x00FF00FFu, 0x0F0F0F0Fu, 0x33333333u, 0x55555555u};   // bit positions with (pos & s) == 0
+  constexpr uint32_t S[4] = {8, 4, 2, 1};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const bool low = (lane & S[i]) == 0;
+    k.rot[i] = low ? 32 - S[i] : S[i];          // low lane takes partner << s, high lane partner >> s
+    k.keep[i] = low ? M[i] : ~M[i];
+  }
+  return k;
+}
+
+// 16x16 bit transpose across a 16-lane group, both 16-bit halves at once
+__device__ inline uint32_t transpose16(uint32_t acc, const DwLaneConst &k) {
+  constexpr int S[4] = {8, 4, 2, 1};
+  static_for<0, 4>([&](auto i) {
+    constexpr int I = decltype(i)::value;
+    const uint32_t partner = (uint32_t)__builtin_amdgcn_ds_swizzle((int)acc, 0x1F | (S[I] << 10));
+    const uint32_t moved = __builtin_amdgcn_alignbit(partner, partner, k.rot[I]);
+    acc = (acc & k.keep[I]) | (moved & ~k.keep[I]);
+  });
+  return acc;
+}
+
 #endif
 
 // Raise a kernel's dynamic LDS limit (> 64 KiB) once per kernel and process: the attribute call
