@@ -65,7 +65,10 @@ __global__ __launch_bounds__(256) void full_dw_kernel(FullDwArgs a) {
 // interleaved concat of four branch tensors (convf: channel J -> branch J%4, channel J/4;
 // models/TT_general_imagenet_v2.py:131-135).  One wave = one image row; lanes = columns.
 // Output: bits (ballot -> row words) or, for the last block, relu'd float32.
-__global__ __launch_bounds__(256) void full_pw_kernel(FullPwArgs a) {
+// 1024 threads share one copy of the group's weights in LDS (119 KiB for 30 -> 240 -> 30): sixteen
+// waves per CU hide the latency of the broadcast LDS reads that one wave per SIMD exposed (3x).
+// (Compile-time sizes with full unrolling were tried and were slower: more registers, same reads.)
+__global__ __launch_bounds__(1024) void full_pw_kernel(FullPwArgs a) {
   extern __shared__ __align__(16) double lds[];
   const int g = blockIdx.x, cin = a.cin, mid = a.mid, cout = a.cout;
   double *w1 = lds;                      // [mid][cin]
@@ -179,8 +182,8 @@ int launch_full_pw(const FullPwArgs &a, hipStream_t s) {
   if (lds > 64 * 1024)
     TT_TRY(ensure_dynamic_lds((const void *)full_pw_kernel, lds));
   const int rows = a.n * a.H;
-  const int chunks = std::max(1, std::min((rows + 3) / 4, std::max(1, 512 / a.groups)));
-  hipLaunchKernelGGL(full_pw_kernel, dim3(a.groups, chunks), dim3(256), lds, s, a);
+  const int chunks = std::max(1, std::min((rows + 15) / 16, std::max(1, 512 / a.groups)));
+  hipLaunchKernelGGL(full_pw_kernel, dim3(a.groups, chunks), dim3(1024), lds, s, a);
   TT_HIP(hipGetLastError());
   return TTNET_OK;
 }
