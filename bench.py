@@ -269,7 +269,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "u16/u64 packed bits + f32",
+            "dtype": "u16/u64 packed bits (gate path); f32 as prescaled fp16x2 split operands on the 16-bit MFMA (stem, lin1, lin2)",
             "data": "synthetic",
             "config": {"workload": (f"TT_general_imagenet_v2_small forward, batch={B} 224x224 per GPU, "
                                     f"bit-packed HIP LUT kernels (BASELINE.json configs[1])") if args.variant == "small"

@@ -14,9 +14,11 @@
  *     last failure on the calling thread is ttnet_last_error().
  *   - a plan is bound to one device; calls on one plan are serialised by the caller;
  *     different plans may run concurrently on different streams.
- *   - the library allocates only inside ttnet_plan_create / _finalize (weights, truth
- *     tables, activation workspace for `max_batch` images); ttnet_forward allocates nothing
- *     and never synchronises, so it can be captured into a hipGraph.
+ *   - device memory is allocated only inside ttnet_plan_create / _finalize / _set_lanes
+ *     (weights, truth tables, one activation workspace for `max_batch` images per lane);
+ *     ttnet_forward never synchronises.  It instantiates a hipGraph of its own the third time
+ *     a batch size is seen (and replays it afterwards); when the caller's stream is itself
+ *     capturing, it records plain launches into the caller's graph instead.
  *   - there is no CPU fallback: without a HIP device every compute entry point fails.
  *
  * Packed activation layouts (all little-endian, LSB first)
