@@ -16,41 +16,59 @@ namespace ttnet {
 
 namespace {
 
-// stem: thread = (image, channel, pooled row); 10 pooled columns -> one row word
-__global__ void va_stem_kernel(const float *__restrict__ x, const float *__restrict__ w, const float *__restrict__ bias,
-                               const float *__restrict__ scale, const float *__restrict__ shift,
-                               uint64_t *__restrict__ rp, int n) {
-  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= (size_t)n * 64 * 10) return;
-  const int py = t % 10, ch = (t / 10) % 64, img = t / 640;
+// stem: one workgroup per image, thread = (channel, pooled row); the zero-padded image lives in LDS
+// (all 64 channel lanes of a wave read the same address: a broadcast), the 27 weights of the
+// channel in registers.  Per pooled pixel the 5x5x3 input patch is read once for its nine
+// convolution outputs.  Taps are accumulated in (c, kh, kw) order; a tap in the zero border adds
+// w * 0, which leaves the sum unchanged.
+__global__ __launch_bounds__(640) void va_stem_kernel(const float *__restrict__ x, const float *__restrict__ w,
+                                                      const float *__restrict__ bias, const float *__restrict__ scale,
+                                                      const float *__restrict__ shift, uint64_t *__restrict__ rp, int n) {
+  __shared__ float img_s[3][34][34];
+  const int img = blockIdx.x;
+  for (int i = threadIdx.x; i < 3 * 34 * 34; i += blockDim.x) {
+    const int c = i / (34 * 34), r = (i / 34) % 34, q = i % 34;
+    const bool in = r >= 1 && r <= 32 && q >= 1 && q <= 32;
+    img_s[c][r][q] = in ? x[((size_t)img * 3 + c) * 1024 + (r - 1) * 32 + (q - 1)] : 0.f;
+  }
+  __syncthreads();
+  const int ch = threadIdx.x & 63, py = threadIdx.x >> 6;            // 10 waves: one pooled row each
   float wr[27];
 #pragma unroll
   for (int i = 0; i < 27; ++i) wr[i] = w[ch * 27 + i];
   const float b = bias[ch], sc = scale[ch], sh = shift[ch];
-  const float *in = x + (size_t)img * 3 * 32 * 32;
   uint64_t out = 0;
   for (int px = 0; px < 10; ++px) {
-    float best = -INFINITY;
+    float acc[3][3];
+#pragma unroll
     for (int dy = 0; dy < 3; ++dy)
-      for (int dx = 0; dx < 3; ++dx) {
-        const int y = 3 * py + dy, xx = 3 * px + dx;
-        float acc = 0.f;
-        for (int c = 0; c < 3; ++c)
-          for (int kh = 0; kh < 3; ++kh) {
-            const int iy = y + kh - 1;
-            if (iy < 0 || iy >= 32) continue;
-            for (int kw = 0; kw < 3; ++kw) {
-              const int ix = xx + kw - 1;
-              if (ix < 0 || ix >= 32) continue;
-              acc = fmaf(in[(c * 32 + iy) * 32 + ix], wr[(c * 3 + kh) * 3 + kw], acc);
-            }
-          }
-        const float v = fmaf(fmaxf(acc + b, 0.f), sc, sh);       // ReLU, then eval BatchNorm
-        best = fmaxf(best, v);
-      }
+#pragma unroll
+      for (int dx = 0; dx < 3; ++dx) acc[dy][dx] = 0.f;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      float patch[5][5];
+#pragma unroll
+      for (int r = 0; r < 5; ++r)
+#pragma unroll
+        for (int q = 0; q < 5; ++q) patch[r][q] = img_s[c][3 * py + r][3 * px + q];
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+          for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx)
+              acc[dy][dx] = fmaf(patch[dy + kh][dx + kw], wr[(c * 3 + kh) * 3 + kw], acc[dy][dx]);
+    }
+    float best = -INFINITY;
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+      for (int dx = 0; dx < 3; ++dx) best = fmaxf(best, fmaf(fmaxf(acc[dy][dx] + b, 0.f), sc, sh));   // ReLU, eval BatchNorm, MaxPool2d(3)
     out |= (uint64_t)(best >= 0.f) << px;
   }
-  rp[((size_t)img * 64 + ch) * 10 + py] = out;
+  if (img < n) rp[((size_t)img * 64 + ch) * 10 + py] = out;
 }
 
 // Block_conv1 / Block_conv2 / out4: thread = (image, channel, output row of the 11x11 plane).
@@ -109,18 +127,27 @@ __global__ void va_c3_kernel(const uint64_t *__restrict__ x_rp, const uint8_t *_
   for (int k = 0; k < 8; ++k) y[((size_t)img * 256 + 128 + 8 * g + k) * 11 + oy] = out[k];
 }
 
-// Flatten (C-major over [256][11][11]) into lin1's fragment-ordered operand (the bit as 0.0 / 1.0:
-// exact in the split format, low term zero).
+// Flatten (C-major over [256][11][11]) into lin1's fragment-ordered operand.  The features are
+// bits: 0.0 / 1.0 is exact in the split format with a zero low term, so only plane 0 is written
+// (plane 1 stays zero from allocation).  Thread = (image, k-step): its 16 features are two aligned
+// 16-byte runs of plane 0 (lane halves k < 8 and k >= 8 of the fragment).
 __global__ void va_feat_kernel(const uint64_t *__restrict__ y, uint16_t *__restrict__ feat_frag, int n) {
-  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= (size_t)n * 256 * 11) return;
-  const int oy = t % 11, ch = (t / 11) % 256, img = t / (11 * 256);
-  const uint64_t r = y[t];
   constexpr int KS = 256 * 121 / 16;
-  for (int ox = 0; ox < 11; ++ox) {
-    const int f = ch * 121 + oy * 11 + ox;
-    store_feature(feat_frag, img, KS, f >> 4, f & 15, ((r >> ox) & 1ull) ? 1.0f : 0.0f);
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (size_t)n * KS) return;
+  const int ks = t % KS, img = t / KS;
+  constexpr uint32_t ONE = 0x4C00u;                    // fp16(1.0 * ACT_PRESCALE)
+  static_assert(ACT_PRESCALE == 16.0f, "ONE encodes the activation prescale");
+  uint32_t half[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+#pragma unroll
+  for (int kk = 0; kk < 16; ++kk) {
+    const int f = 16 * ks + kk, ch = f / 121, rem = f - 121 * ch, oy = rem / 11, ox = rem - 11 * oy;
+    const uint32_t bit = (uint32_t)(y[((size_t)img * 256 + ch) * 11 + oy] >> ox) & 1u;
+    half[kk >> 3][(kk & 7) >> 1] |= (bit ? ONE : 0u) << (16 * (kk & 1));
   }
+  uint4 *dst = (uint4 *)feat_frag + ((((size_t)(img >> 5) * KS + ks) * SPLIT_PLANES + 0) * 64 + (img & 31));
+  dst[0] = make_uint4(half[0][0], half[0][1], half[0][2], half[0][3]);
+  dst[32] = make_uint4(half[1][0], half[1][1], half[1][2], half[1][3]);
 }
 
 __global__ void va_frag_to_flat_kernel(const uint16_t *__restrict__ af, float *__restrict__ out, int n) {
@@ -135,8 +162,7 @@ __global__ void va_frag_to_flat_kernel(const uint16_t *__restrict__ af, float *_
 
 int launch_va_stem(const float *x, const float *w, const float *bias, const float *scale, const float *shift,
                    uint64_t *rp, int n, hipStream_t s) {
-  const size_t t = (size_t)n * 640;
-  hipLaunchKernelGGL(va_stem_kernel, dim3((unsigned)((t + 127) / 128)), dim3(128), 0, s, x, w, bias, scale, shift, rp, n);
+  hipLaunchKernelGGL(va_stem_kernel, dim3(n), dim3(640), 0, s, x, w, bias, scale, shift, rp, n);
   TT_HIP(hipGetLastError());
   return TTNET_OK;
 }
@@ -152,8 +178,8 @@ int launch_va_block(const uint64_t *x_rp, const void *t1, const void *t2, const 
 }
 
 int launch_va_feat(const uint64_t *y, void *feat_frag, int n, hipStream_t s) {
-  const size_t t = (size_t)n * 256 * 11;
-  hipLaunchKernelGGL(va_feat_kernel, dim3((unsigned)((t + 127) / 128)), dim3(128), 0, s, y, (uint16_t *)feat_frag, n);
+  const size_t t = (size_t)n * (256 * 121 / 16);
+  hipLaunchKernelGGL(va_feat_kernel, dim3((unsigned)((t + 255) / 256)), dim3(256), 0, s, y, (uint16_t *)feat_frag, n);
   TT_HIP(hipGetLastError());
   return TTNET_OK;
 }

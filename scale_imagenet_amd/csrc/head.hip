@@ -21,6 +21,7 @@
 // Bound: lin1 16-bit MFMA (3 MFMA flops per algorithmic flop) / HBM (66 MB of split weights
 // read once per batch); lin2 latency.
 
+#include <algorithm>
 #include <cmath>
 
 #include "ttnet_common.h"
@@ -280,10 +281,12 @@ __global__ void permute_lin1_kernel(const float *__restrict__ w1, float *__restr
 }  // namespace
 
 int gemm_f16x2_splits(int M, int N, int KS) {
+  // the most K-slices (a divisor of the k-step count, slices of at least 8 k-steps) that still give
+  // at most one workgroup per CU
   const int tiles = ((M + G_BM - 1) / G_BM) * ((N + G_BN - 1) / G_BN);
-  int s = 1;
-  while (s * 2 * tiles <= 256 && KS % (s * 2) == 0 && (KS / (s * 2)) % G_KS == 0 && KS / (s * 2) >= 8) s *= 2;
-  return s;
+  for (int s = std::min(std::min(256 / std::max(1, tiles), KS / 8), 128); s > 1; --s)   // (<= 128: the reduce pass reads every slab)
+    if (KS % s == 0) return s;
+  return 1;
 }
 
 int launch_gemm_f16x2(const void *Af, const void *Bf, float *part, int M, int N, int K, int splits, hipStream_t s) {
