@@ -381,6 +381,32 @@ def test_truth_table_export_from_gpu_tables(dev, tmp_path):
     assert compared >= 10
 
 
+def test_ragged_batches_plan_regrowth_and_lanes(dev):
+    """Batch sizes around the 32-image tile edges, a forward larger than the reserved workspace
+    (the plan is rebuilt with the lanes it had), and both input kinds on both lanes: every result
+    equals the corresponding rows of one large forward."""
+    spec, st = spec_and_state("small")
+    m = ttnet.TT_vf_19lv3_imgnet_small(args_for("small"))
+    m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in st.items()})
+    m = m.to(dev).eval().reserve(40).set_lanes(2)
+    u8 = synth.synth_images_u8(70)
+    x = torch.from_numpy(synth.normalize_u8(u8)).to(dev)
+    with torch.no_grad():
+        small = {n: m(x[:n]).clone() for n in (1, 2, 31, 33, 40)}
+        big = m(x).clone()                           # 70 > 40: the plan grows
+        assert m._any_plan().query("lanes") == 2 and m._any_plan().query("max_batch") >= 70
+        for n, y in small.items():
+            assert torch.equal(y, big[:n]), n
+        for rep in range(4):
+            a, b = m(x, lane=0), m(x, lane=1)
+        xu = torch.from_numpy(np.ascontiguousarray(u8[:33].transpose(0, 2, 3, 1))).to(dev)
+        for rep in range(4):
+            yu = m.forward_u8(xu, lane=rep % 2)
+    torch.cuda.synchronize()
+    assert torch.equal(a, big) and torch.equal(b, big)
+    assert (yu - big[:33]).abs().max().item() <= 1e-3      # equal unless a stem near tie flips
+
+
 def test_majority_and_padding_edges(model, variant, dev):
     """Edge inputs of the integer path: all-zero and all-one stem bits, checked against the
     bit oracle with the GPU's own tables."""
