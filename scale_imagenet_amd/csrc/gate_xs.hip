@@ -2,16 +2,61 @@
 // models/TT_general_imagenet_v2_xsmall.py:21-148 -- 2x2/s2 depthwise windows, 4-channel
 // grouped 1x1 blocks, convf groups of one channel x four branches.
 //
-// Every truth table has 16 entries (a 16-bit word per output bit), so the whole block's tables
-// are a few KiB and the evaluation is pure register bit arithmetic on row-packed planes
-// (uint64 per image row, bit x = pixel x); no channel-packed layout is needed.  The work is
-// ~40x smaller than the small model's; these kernels favour clarity over the last cycle.
+// Every truth table has 16 entries, so the whole block's tables are a few KiB and the evaluation
+// is pure register bit arithmetic on row-packed planes (uint64 per image row, bit x = pixel x); no
+// channel-packed layout is needed.  The tables are evaluated BIT-SLICED: a 4-input function is a
+// 15-multiplexer tree (table bits -> x0 -> x1 -> x2 -> x3, one v_bfi per 32 pixels and
+// multiplexer), so one pass yields the function at all 64 pixel positions of a row word at once
+// instead of one lookup per pixel.  Stride-2 windows and the 2x2 majority are evaluated at every
+// bit position on the un-decimated rows and the even positions are then squeezed together.
 
 #include "ttnet_common.h"
 
 namespace ttnet {
 
 namespace {
+
+// f(x0,x1,x2,x3) at all 64 bit positions; bit i of t = f at index i = x0 + 2 x1 + 4 x2 + 8 x3
+__device__ inline uint64_t lut4_rows(uint32_t t, uint64_t x0, uint64_t x1, uint64_t x2, uint64_t x3) {
+  auto mux = [](uint64_t sel, uint64_t hi, uint64_t lo) { return lo ^ ((hi ^ lo) & sel); };
+  uint64_t a[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const uint32_t c0 = (uint32_t)((int32_t)(t << (31 - 2 * j)) >> 31);        // table bit 2j as 0 / ~0
+    const uint32_t c1 = (uint32_t)((int32_t)(t << (30 - 2 * j)) >> 31);        // table bit 2j+1
+    a[j] = mux(x0, ((uint64_t)c1 << 32) | c1, ((uint64_t)c0 << 32) | c0);
+  }
+  const uint64_t b0 = mux(x1, a[1], a[0]), b1 = mux(x1, a[3], a[2]), b2 = mux(x1, a[5], a[4]), b3 = mux(x1, a[7], a[6]);
+  return mux(x3, mux(x2, b3, b2), mux(x2, b1, b0));
+}
+
+// bits 0, 2, 4, ... of x squeezed into bits 0, 1, 2, ... (32 results)
+__device__ inline uint64_t even_bits(uint64_t x) {
+  x &= 0x5555555555555555ull;
+  x = (x | (x >> 1)) & 0x3333333333333333ull;
+  x = (x | (x >> 2)) & 0x0F0F0F0F0F0F0F0Full;
+  x = (x | (x >> 4)) & 0x00FF00FF00FF00FFull;
+  x = (x | (x >> 8)) & 0x0000FFFF0000FFFFull;
+  return (x | (x >> 16)) & 0x00000000FFFFFFFFull;
+}
+
+// column k of a 16-entry table of bytes (entries 0-7 in w0, 8-15 in w1): bit i = bit k of entry i
+__device__ inline uint32_t table_column(uint64_t w0, uint64_t w1, int k) {
+  auto gather = [](uint64_t w) {            // bit 0 of every byte -> the low 8 bits
+    w &= 0x0101010101010101ull;
+    w |= w >> 7;
+    w |= w >> 14;
+    w |= w >> 28;
+    return (uint32_t)w & 0xFFu;
+  };
+  return gather(w0 >> k) | (gather(w1 >> k) << 8);
+}
+
+// act(AvgPool2d(2)(.) - 0.5) of rows (e, o): at least two of the four bits of every 2x2 cell
+__device__ inline uint64_t majority_rows(uint64_t e, uint64_t o, int cells) {
+  const uint64_t ae = e & (e >> 1), xe = e ^ (e >> 1), ao = o & (o >> 1), xo = o ^ (o >> 1);
+  return even_bits(ae | ao | (xe & xo)) & ((1ull << cells) - 1ull);
+}
 
 // one thread = (image, 4-channel group, output row): Block_conv1, Block_conv2, Block_conv3 +
 // majority, majority of x, all four branch rows of its 4 channels, already zero-padded.
@@ -23,62 +68,40 @@ __global__ void xs_branches_kernel(GateBlockArgs a, const uint32_t *t_dw1, const
   const int oy = t % a.Ho, g = (t / a.Ho) % G, n = t / ((size_t)a.Ho * G);
   const int py = oy - a.off34;                       // pooled row feeding out3/out4 (may be outside)
   const bool pooled_ok = py >= 0 && py < a.H / 2;
-  uint64_t xe[4] = {0, 0, 0, 0}, xo[4] = {0, 0, 0, 0};   // rows 2py, 2py+1 of the 4 channels
-  uint32_t c3tab[16];
-#pragma unroll
-  for (int i = 0; i < 16; ++i) c3tab[i] = t_c3[g * 16 + i];
-  uint64_t r3[4] = {0, 0, 0, 0};
+  const int cells = a.W / 2;
+  uint64_t r3[4] = {0, 0, 0, 0}, r4[4] = {0, 0, 0, 0};
   if (pooled_ok) {
+    uint64_t xe[4], xo[4];                            // rows 2py, 2py+1 of the 4 channels
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const uint64_t *pl = a.x_rp + ((size_t)n * a.C + 4 * g + k) * a.H;
       xe[k] = pl[2 * py];
       xo[k] = pl[2 * py + 1];
     }
-    // conv3 at full resolution on both rows, then 2x2 majority
-    for (int px = 0; px < a.W / 2; ++px) {
-      uint32_t cnt[4] = {0, 0, 0, 0};
+    const uint64_t w0 = *(const uint64_t *)(t_c3 + g * 16), w1 = *(const uint64_t *)(t_c3 + g * 16 + 8);
 #pragma unroll
-      for (int d = 0; d < 4; ++d) {
-        const int x = 2 * px + (d & 1);
-        uint32_t idx = 0;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) idx |= (uint32_t)((((d >> 1) ? xo[k] : xe[k]) >> x) & 1ull) << k;
-        const uint32_t out = c3tab[idx];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) cnt[k] += (out >> k) & 1u;
-      }
-#pragma unroll
-      for (int k = 0; k < 4; ++k) r3[k] |= (uint64_t)(cnt[k] >= 2) << (px + a.off34);
+    for (int k = 0; k < 4; ++k) {
+      const uint32_t tk = table_column(w0, w1, k);   // conv3 output bit k as a function of the 4 input channels
+      const uint64_t ce = lut4_rows(tk, xe[0], xe[1], xe[2], xe[3]), co = lut4_rows(tk, xo[0], xo[1], xo[2], xo[3]);
+      r3[k] = majority_rows(ce, co, cells) << a.off34;
+      r4[k] = majority_rows(xe[k], xo[k], cells) << a.off34;
     }
   }
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     const int c = 4 * g + k;
-    // out4 = majority of x itself
-    uint64_t r4 = 0;
-    if (pooled_ok)
-      for (int px = 0; px < a.W / 2; ++px) {
-        const uint32_t s = (uint32_t)((xe[k] >> (2 * px)) & 3ull), u = (uint32_t)((xo[k] >> (2 * px)) & 3ull);
-        r4 |= (uint64_t)(__popc(s) + __popc(u) >= 2) << (px + a.off34);
-      }
-    // depthwise 2x2 / stride 2 / pad 1: input rows 2oy-1, 2oy; padded column index = x + 1
+    // depthwise 2x2 / stride 2 / pad 1: input rows 2oy-1, 2oy; padded column index = x + 1.  The
+    // window of output column ox is bits 2ox, 2ox+1 of both padded rows: index bit = kh*2 + kw.
     const uint64_t *pl = a.x_rp + ((size_t)n * a.C + c) * a.H;
     const int iy0 = 2 * oy - 1;
     const uint64_t ra = (iy0 >= 0 && iy0 < a.H) ? pl[iy0] << 1 : 0ull;
     const uint64_t rb = (iy0 + 1 < a.H) ? pl[iy0 + 1] << 1 : 0ull;
-    const uint32_t ta = t_dw1[c], tb = t_dw2[c];       // 16 entries, bit idx; idx bit = kh*2 + kw
-    uint64_t r1 = 0, r2 = 0;
-    for (int ox = 0; ox < a.Wo; ++ox) {
-      const uint32_t idx = (uint32_t)((ra >> (2 * ox)) & 3ull) | ((uint32_t)((rb >> (2 * ox)) & 3ull) << 2);
-      r1 |= (uint64_t)((ta >> idx) & 1u) << ox;
-      r2 |= (uint64_t)((tb >> idx) & 1u) << ox;
-    }
+    const uint64_t keep = (1ull << a.Wo) - 1ull;
     const size_t dst = ((size_t)n * a.C + c) * a.Ho + oy;
-    o1[dst] = r1;
-    o2[dst] = r2;
+    o1[dst] = even_bits(lut4_rows(t_dw1[c], ra, ra >> 1, rb, rb >> 1)) & keep;
+    o2[dst] = even_bits(lut4_rows(t_dw2[c], ra, ra >> 1, rb, rb >> 1)) & keep;
     o3[dst] = r3[k];
-    o4[dst] = r4;
+    o4[dst] = r4[k];
   }
 }
 
@@ -90,15 +113,10 @@ __global__ void xs_pf_kernel(int n, int C, int Ho, int Wo, int cout_g, const uin
   if (t >= (size_t)n * C * Ho) return;
   const int oy = t % Ho, c = (t / Ho) % C, img = t / ((size_t)Ho * C);
   const uint64_t a = o1[t], b = o2[t], d = o3[t], e = o4[t];
-  uint64_t rows[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  for (int x = 0; x < Wo; ++x) {
-    const uint32_t idx = (uint32_t)((a >> x) & 1ull) | ((uint32_t)((b >> x) & 1ull) << 1) |
-                         ((uint32_t)((d >> x) & 1ull) << 2) | ((uint32_t)((e >> x) & 1ull) << 3);
-    const uint32_t v = t_cf[c * 16 + idx];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) rows[k] |= (uint64_t)((v >> k) & 1u) << x;
-  }
-  for (int k = 0; k < cout_g; ++k) out_rp[((size_t)img * C * cout_g + c * cout_g + k) * Ho + oy] = rows[k];
+  const uint64_t w0 = *(const uint64_t *)(t_cf + c * 16), w1 = *(const uint64_t *)(t_cf + c * 16 + 8);
+  const uint64_t keep = (1ull << Wo) - 1ull;
+  for (int k = 0; k < cout_g; ++k)
+    out_rp[((size_t)img * C * cout_g + c * cout_g + k) * Ho + oy] = lut4_rows(table_column(w0, w1, k), a, b, d, e) & keep;
 }
 
 // convf of the last block (float table [C][16][cout_g]) + AvgPool2d(2), features written as
