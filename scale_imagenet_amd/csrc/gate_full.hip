@@ -86,19 +86,25 @@ __global__ __launch_bounds__(1024) void full_pw_kernel(FullPwArgs a) {
   }
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
-  const int rows = a.n * a.H;
-  for (int t = blockIdx.y * nwaves + wave; t < rows; t += gridDim.y * nwaves) {
-    const int n = t / a.H, y = t % a.H;
-    const bool live = lane < a.W;
+  // A wave covers as many whole image rows as fit its 64 lanes (one row of 56 pixels, two of 29,
+  // four of 16, seven of 9): lane = (row r of the bundle, column x).  (One row per wave left 55-85 % of
+  // the lanes idle in the later blocks.)
+  const int rpw = 64 / a.W, bundles = (a.H + rpw - 1) / rpw;
+  const int r = lane / a.W, x = lane - r * a.W;
+  const int tasks = a.n * bundles;
+  for (int t = blockIdx.y * nwaves + wave; t < tasks; t += gridDim.y * nwaves) {
+    const int n = t / bundles, y = (t % bundles) * rpw + r;
+    const bool live = r < rpw && y < a.H;
     // this pixel's `cin` input bits
     uint32_t in = 0;
-    for (int j = 0; j < cin; ++j) {
-      const int J = cin * g + j;
-      uint64_t row;
-      if (a.interleaved) row = a.src[J & 3][((size_t)n * a.Csrc + (J >> 2)) * a.H + y];
-      else row = a.src[0][((size_t)n * a.Csrc + J) * a.H + y];
-      in |= (uint32_t)((row >> lane) & 1ull) << j;
-    }
+    if (live)
+      for (int j = 0; j < cin; ++j) {
+        const int J = cin * g + j;
+        uint64_t row;
+        if (a.interleaved) row = a.src[J & 3][((size_t)n * a.Csrc + (J >> 2)) * a.H + y];
+        else row = a.src[0][((size_t)n * a.Csrc + J) * a.H + y];
+        in |= (uint32_t)((row >> x) & 1ull) << j;
+      }
     double acc[30];
 #pragma unroll
     for (int o = 0; o < 30; ++o) acc[o] = 0.0;
@@ -116,10 +122,11 @@ __global__ __launch_bounds__(1024) void full_pw_kernel(FullPwArgs a) {
       if (o >= cout) break;
       const double pre = acc[o] * s2[o] + t2[o];
       if (a.out_float) {
-        if (live) a.out_float[(((size_t)n * a.Cout + g * cout + o) * a.H + y) * a.W + lane] = (float)(pre > 0.0 ? pre : 0.0);
+        if (live) a.out_float[(((size_t)n * a.Cout + g * cout + o) * a.H + y) * a.W + x] = (float)(pre > 0.0 ? pre : 0.0);
       } else {
         const uint64_t m64 = __ballot(live && pre >= 0.0);
-        if (lane == 0) a.out_rp[((size_t)n * a.Cout + g * cout + o) * a.H + y] = m64;
+        if (live && x == 0)                               // the first lane of every row writes its row word
+          a.out_rp[((size_t)n * a.Cout + g * cout + o) * a.H + y] = (m64 >> (r * a.W)) & ((1ull << a.W) - 1ull);
       }
     }
   }
@@ -181,7 +188,7 @@ int launch_full_pw(const FullPwArgs &a, hipStream_t s) {
   }
   if (lds > 64 * 1024)
     TT_TRY(ensure_dynamic_lds((const void *)full_pw_kernel, lds));
-  const int rows = a.n * a.H;
+  const int rpw = 64 / a.W, rows = a.n * ((a.H + rpw - 1) / rpw);        // row bundles (tasks) of the launch
   const int chunks = std::max(1, std::min((rows + 15) / 16, std::max(1, 512 / a.groups)));
   hipLaunchKernelGGL(full_pw_kernel, dim3(a.groups, chunks), dim3(1024), lds, s, a);
   TT_HIP(hipGetLastError());

@@ -648,7 +648,9 @@ int run_full_block(ttnet_plan *pl, size_t i, int n, hipStream_t s) {
     a.w1 = wts(b, ".conv1.weight"); a.w2 = wts(b, ".conv2.weight");
     a.s1 = b.s1; a.t1 = b.t1; a.s2 = b.s2; a.t2 = b.t2;
     a.out = o64[br];
-    TT_TIMED(pl, br ? "full.conv2" : "full.conv1", s, launch_full_dw(a, s));
+    static const char *const kDw[2][4] = {{"full.conv1.f4", "full.conv1.f5", "full.conv1.f6", "full.conv1.f7"},
+                                         {"full.conv2.f4", "full.conv2.f5", "full.conv2.f6", "full.conv2.f7"}};
+    TT_TIMED(pl, kDw[br][std::min<size_t>(i, 3)], s, launch_full_dw(a, s));
   }
   {
     const BlockTT &b = mh.c3;
@@ -659,7 +661,8 @@ int run_full_block(ttnet_plan *pl, size_t i, int n, hipStream_t s) {
     a.w1 = wts(b, ".conv1.weight"); a.w2 = wts(b, ".conv2.weight");
     a.s1 = b.s1; a.t1 = b.t1; a.s2 = b.s2; a.t2 = b.t2;
     a.out_rp = mh.c3_tmp; a.out_float = nullptr;
-    TT_TIMED(pl, "full.conv3", s, launch_full_pw(a, s));
+    static const char *const kC3[4] = {"full.conv3.f4", "full.conv3.f5", "full.conv3.f6", "full.conv3.f7"};
+    TT_TIMED(pl, kC3[std::min<size_t>(i, 3)], s, launch_full_pw(a, s));
     TT_TIMED(pl, "full.maj3", s,
              launch_rp_majority(mh.c3_tmp, o64[2], n, mh.C, mh.H, mh.W, mh.Ho, mh.off34, mh.off34, s));
     TT_TIMED(pl, "full.maj4", s,
@@ -680,7 +683,8 @@ int run_full_block(ttnet_plan *pl, size_t i, int n, hipStream_t s) {
       TT_TIMED(pl, "full.pool", s, launch_full_pool_split(pl->last_float, pl->feat, n, b.g.out_planes, mh.Ho, mh.Wo, s));
     } else {
       a.out_rp = pl->x_rp[i + 1]; a.out_float = nullptr;
-      TT_TIMED(pl, "full.convf", s, launch_full_pw(a, s));
+      static const char *const kCf[4] = {"full.convf.f4", "full.convf.f5", "full.convf.f6", "full.convf.f7"};
+      TT_TIMED(pl, kCf[std::min<size_t>(i, 3)], s, launch_full_pw(a, s));
     }
   }
   return TTNET_OK;
