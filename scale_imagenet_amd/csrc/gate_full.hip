@@ -10,6 +10,8 @@
 // Everything stays on row-packed planes (uint64 per image row).  Bound: fp64 VALU
 // (~0.8 GFLOP per image); this first version is written for parity, not speed.
 
+#include <cstdlib>
+
 #include "ttnet_common.h"
 
 namespace ttnet {
@@ -132,6 +134,189 @@ __global__ __launch_bounds__(1024) void full_pw_kernel(FullPwArgs a) {
   }
 }
 
+// The same block with the weights in SGPRs.  Every lane of a wave needs the same weight at the same
+// time, so the float64 record of hidden unit m ([30 input weights][COUT output weights], a.wd) is
+// fetched with scalar loads (wave-uniform address) instead of one LDS broadcast read per weight and
+// lane -- the LDS version is bound by the LDS instruction rate (14,400 reads per task).  The input
+// bits are expanded once per task to 0.0 / 1.0, so that layer 1 is an fma per input (w * 1 + s and
+// w * 0 + s round like the conditional add; same order, j ascending).  No LDS at all.
+template <int COUT>
+__global__ __launch_bounds__(256) void full_pw_sgpr_kernel(FullPwArgs a) {
+  constexpr int CIN = 30;
+  const int g = blockIdx.x, mid = a.mid;
+  const double *__restrict__ wg = a.wd + (size_t)g * mid * (CIN + COUT);
+  const double *__restrict__ s1 = a.s1 + (size_t)g * mid, *__restrict__ t1 = a.t1 + (size_t)g * mid;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nwaves = blockDim.x >> 6;
+  const int rpw = 64 / a.W, bundles = (a.H + rpw - 1) / rpw;
+  const int r = lane / a.W, x = lane - r * a.W;
+  const int tasks = a.n * bundles;
+  for (int t = blockIdx.y * nwaves + wave; t < tasks; t += gridDim.y * nwaves) {
+    const int n = t / bundles, y = (t % bundles) * rpw + r;
+    const bool live = r < rpw && y < a.H;
+    double xb[CIN];
+#pragma unroll
+    for (int j = 0; j < CIN; ++j) {
+      const int J = CIN * g + j;
+      uint64_t row = 0;
+      if (live) row = a.interleaved ? a.src[J & 3][((size_t)n * a.Csrc + (J >> 2)) * a.H + y] : a.src[0][((size_t)n * a.Csrc + J) * a.H + y];
+      xb[j] = ((row >> x) & 1ull) ? 1.0 : 0.0;
+    }
+    double acc[COUT];
+#pragma unroll
+    for (int o = 0; o < COUT; ++o) acc[o] = 0.0;
+    for (int m = 0; m < mid; ++m) {
+      const double *__restrict__ rec = wg + (size_t)m * (CIN + COUT);       // wave-uniform: scalar loads
+      // (chunks of 10 weights: 20 SGPRs live at a time; the whole 60-weight record at once spills SGPRs)
+      double s = 0.0;
+      static_for<0, CIN / 10>([&](auto cc) {
+        constexpr int J0 = decltype(cc)::value * 10;
+#pragma unroll
+        for (int j = J0; j < J0 + 10; ++j) s = fma(rec[j], xb[j], s);
+        __builtin_amdgcn_sched_barrier(0);
+      });
+      const double h = gelu_exact(s * s1[m] + t1[m]);
+      static_for<0, (COUT + 9) / 10>([&](auto cc) {
+        constexpr int O0 = decltype(cc)::value * 10, O1 = O0 + 10 < COUT ? O0 + 10 : COUT;
+#pragma unroll
+        for (int o = O0; o < O1; ++o) acc[o] = fma(h, rec[CIN + o], acc[o]);
+        __builtin_amdgcn_sched_barrier(0);
+      });
+    }
+#pragma unroll
+    for (int o = 0; o < COUT; ++o) {
+      const double pre = acc[o] * a.s2[g * COUT + o] + a.t2[g * COUT + o];
+      if (a.out_float) {
+        if (live) a.out_float[(((size_t)n * a.Cout + g * COUT + o) * a.H + y) * a.W + x] = (float)(pre > 0.0 ? pre : 0.0);
+      } else {
+        const uint64_t m64 = __ballot(live && pre >= 0.0);
+        if (live && x == 0)
+          a.out_rp[((size_t)n * a.Cout + g * COUT + o) * a.H + y] = (m64 >> (r * a.W)) & ((1ull << a.W) - 1ull);
+      }
+    }
+  }
+}
+
+// The same block on the float64 matrix instruction v_mfma_f64_16x16x4_f64 (operand layouts probed in
+// tools/ubench/mfma_f64_layout.hip: A lane l = A[l%16][l/16], B lane l = B[l/16][l%16], D register i of
+// lane l = D[4i + l/16][l%16]).  Both layers are small GEMMs over the 64 pixels of a task:
+//   layer 1   H[240 x 64] = W1[240 x 30] * X[30 x 64]      (X = the input bits as 0.0 / 1.0)
+//   layer 2   O[cout x 64] = W2[cout x 240] * gelu(bn1(H))
+// walked in 15 tiles of 16 hidden units: the D registers of a layer-1 tile are, after BN + GELU,
+// directly the B operands of four layer-2 k-steps (register i = hidden rows 4i .. 4i+3 of the tile).
+// Weights sit in LDS in fragment order and are read once per tile and wave (240 LDS reads per task
+// instead of 14,400 broadcast reads); no operand is broadcast lane by lane.  Sums are formed in a
+// different order than the oracle's (blocks of four products): a 1e-16 relative effect, i.e. only
+// an exact tie could turn.
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+
+template <int OT>      // 16-row output tiles: 2 (cout = 30) or 1 (cout = 15)
+__global__ __launch_bounds__(512) void full_pw_mfma_kernel(FullPwArgs a) {
+  extern __shared__ __align__(16) double lds[];
+  constexpr int CIN = 30, MT = 15, KS1 = 8;              // 240 hidden units, K = 30 padded to 32
+  double *w1f = lds;                                     // [MT][KS1][64]
+  double *w2f = w1f + MT * KS1 * 64;                     // [MT][4][OT][64]
+  double *s1 = w2f + MT * 4 * OT * 64, *t1 = s1 + 16 * MT;
+  const int g = blockIdx.x, cout = a.cout, mid = 16 * MT;
+  for (int i = threadIdx.x; i < MT * KS1 * 64; i += blockDim.x) {
+    const int l = i & 63, ks = (i >> 6) % KS1, mt = i / (64 * KS1);
+    const int m = 16 * mt + (l & 15), k = 4 * ks + (l >> 4);
+    w1f[i] = k < CIN ? (double)a.w1[((size_t)g * mid + m) * CIN + k] : 0.0;
+  }
+  for (int i = threadIdx.x; i < MT * 4 * OT * 64; i += blockDim.x) {
+    const int l = i & 63, ot = (i >> 6) % OT, ii = (i / (64 * OT)) & 3, mt = i / (64 * OT * 4);
+    const int o = 16 * ot + (l & 15), hid = 16 * mt + 4 * ii + (l >> 4);
+    w2f[i] = o < cout ? (double)a.w2[((size_t)g * cout + o) * mid + hid] : 0.0;
+  }
+  for (int i = threadIdx.x; i < mid; i += blockDim.x) {
+    s1[i] = a.s1[g * mid + i];
+    t1[i] = a.t1[g * mid + i];
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nwaves = blockDim.x >> 6;
+  const int lg = lane >> 4, ln = lane & 15;
+  const int rpw = 64 / a.W, bundles = (a.H + rpw - 1) / rpw;
+  const int r = lane / a.W, x = lane - r * a.W;
+  const int tasks = a.n * bundles;
+  for (int t = blockIdx.y * nwaves + wave; t < tasks; t += gridDim.y * nwaves) {
+    const int n = t / bundles, y0 = (t % bundles) * rpw, y = y0 + r;
+    const bool live = r < rpw && y < a.H;
+    uint32_t in = 0;                                     // this lane's pixel: its 30 input bits
+    if (live)
+#pragma unroll
+      for (int j = 0; j < CIN; ++j) {
+        const int J = CIN * g + j;
+        const uint64_t row = a.interleaved ? a.src[J & 3][((size_t)n * a.Csrc + (J >> 2)) * a.H + y]
+                                           : a.src[0][((size_t)n * a.Csrc + J) * a.H + y];
+        in |= (uint32_t)((row >> x) & 1ull) << j;
+      }
+    // B fragments of layer 1: lane l of (k-step ks, pixel tile nt) = bit 4ks + l/16 of pixel 16nt + l%16
+    double xf[KS1][4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+      const uint32_t inp = (uint32_t)__shfl((int)in, 16 * nt + ln) >> lg;
+#pragma unroll
+      for (int ks = 0; ks < KS1; ++ks) xf[ks][nt] = ((inp >> (4 * ks)) & 1u) ? 1.0 : 0.0;
+    }
+    f64x4 acc[OT][4];
+#pragma unroll
+    for (int ot = 0; ot < OT; ++ot)
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) acc[ot][nt] = f64x4{0.0, 0.0, 0.0, 0.0};
+    for (int mt = 0; mt < MT; ++mt) {
+      f64x4 d[4];
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) d[nt] = f64x4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int ks = 0; ks < KS1; ++ks) {
+        const double wa = w1f[(mt * KS1 + ks) * 64 + lane];
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) d[nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(wa, xf[ks][nt], d[nt], 0, 0, 0);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {                       // register i = hidden unit 16mt + 4i + l/16
+        const double sc = s1[16 * mt + 4 * i + lg], sh = t1[16 * mt + 4 * i + lg];
+        double h[4];
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) h[nt] = gelu_exact(d[nt][i] * sc + sh);
+#pragma unroll
+        for (int ot = 0; ot < OT; ++ot) {
+          const double wb = w2f[((mt * 4 + i) * OT + ot) * 64 + lane];
+#pragma unroll
+          for (int nt = 0; nt < 4; ++nt) acc[ot][nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(wb, h[nt], acc[ot][nt], 0, 0, 0);
+        }
+      }
+    }
+    // acc[ot][nt][i] = output channel 16ot + 4i + l/16 at pixel 16nt + l%16
+#pragma unroll
+    for (int ot = 0; ot < OT; ++ot)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int o = 16 * ot + 4 * i + lg;               // this lane's channel of the quartet
+        const bool o_ok = o < cout;
+        const double sc = o_ok ? a.s2[g * cout + o] : 0.0, sh = o_ok ? a.t2[g * cout + o] : -1.0;
+        if (a.out_float) {
+#pragma unroll
+          for (int nt = 0; nt < 4; ++nt) {
+            const int p = 16 * nt + ln, pr = p / a.W, px = p - pr * a.W, py = y0 + pr;
+            const double pre = acc[ot][nt][i] * sc + sh;
+            if (o_ok && pr < rpw && py < a.H)
+              a.out_float[(((size_t)n * a.Cout + g * cout + o) * a.H + py) * a.W + px] = (float)(pre > 0.0 ? pre : 0.0);
+          }
+        } else {
+          // one ballot per pixel tile: bits 16q .. 16q+15 = channel quartet member q over the tile's 16 pixels
+          uint64_t bal[4];
+#pragma unroll
+          for (int nt = 0; nt < 4; ++nt) bal[nt] = __ballot(acc[ot][nt][i] * sc + sh >= 0.0);
+          // lane (q = l/16, row r' = l%16 < rpw) writes the row word of channel 16ot + 4i + q, image row y0 + r'
+          const uint64_t mine = ((bal[0] >> (16 * lg)) & 0xFFFFull) | (((bal[1] >> (16 * lg)) & 0xFFFFull) << 16) |
+                                (((bal[2] >> (16 * lg)) & 0xFFFFull) << 32) | (((bal[3] >> (16 * lg)) & 0xFFFFull) << 48);
+          if (o_ok && ln < rpw && y0 + ln < a.H)
+            a.out_rp[((size_t)n * a.Cout + g * cout + o) * a.H + y0 + ln] = (mine >> (ln * a.W)) & ((1ull << a.W) - 1ull);
+        }
+      }
+  }
+}
+
 // act(AvgPool2d(2)(x) - 0.5): floor-cropped 2x2 majority on row-packed planes, placed at (pad_t, pad_l)
 __global__ void rp_majority_kernel(const uint64_t *x, uint64_t *out, int n, int C, int H, int W, int Ho, int pad_t,
                                    int pad_l) {
@@ -177,6 +362,29 @@ int launch_full_dw(const FullDwArgs &a, hipStream_t s) {
 }
 
 int launch_full_pw(const FullPwArgs &a, hipStream_t s) {
+  if (a.cin == 30 && a.mid == 240 && (a.cout == 30 || a.cout == 15) && a.W <= 64 && !getenv("TTNET_FULL_NO_MFMA")) {
+    const int ot = a.cout == 30 ? 2 : 1;
+    const size_t lds = sizeof(double) * ((size_t)15 * 8 * 64 + (size_t)15 * 4 * ot * 64 + 2 * 240);
+    const int rpw = 64 / a.W, tasks = a.n * ((a.H + rpw - 1) / rpw);
+    const int chunks = std::max(1, std::min((tasks + 7) / 8, std::max(1, 512 / a.groups)));
+    if (ot == 2) {
+      TT_TRY(ensure_dynamic_lds((const void *)full_pw_mfma_kernel<2>, lds));
+      hipLaunchKernelGGL(full_pw_mfma_kernel<2>, dim3(a.groups, chunks), dim3(512), lds, s, a);
+    } else {
+      TT_TRY(ensure_dynamic_lds((const void *)full_pw_mfma_kernel<1>, lds));
+      hipLaunchKernelGGL(full_pw_mfma_kernel<1>, dim3(a.groups, chunks), dim3(512), lds, s, a);
+    }
+    TT_HIP(hipGetLastError());
+    return TTNET_OK;
+  }
+  if (a.wd && a.cin == 30 && (a.cout == 30 || a.cout == 15) && a.W <= 64) {
+    const int rpw = 64 / a.W, tasks = a.n * ((a.H + rpw - 1) / rpw);
+    const int chunks = std::max(1, std::min((tasks + 3) / 4, std::max(1, 2048 / a.groups)));
+    if (a.cout == 30) hipLaunchKernelGGL(full_pw_sgpr_kernel<30>, dim3(a.groups, chunks), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(full_pw_sgpr_kernel<15>, dim3(a.groups, chunks), dim3(256), 0, s, a);
+    TT_HIP(hipGetLastError());
+    return TTNET_OK;
+  }
   if (a.cin > 32 || a.cout > 30 || a.W > 64) {
     set_error("full_pw: unsupported group %d -> %d", a.cin, a.cout);
     return TTNET_E_UNSUPPORTED;
