@@ -62,6 +62,64 @@ __global__ __launch_bounds__(256) void full_dw_kernel(FullDwArgs a) {
   }
 }
 
+// The same block with per-row partial sums from tables: the pre-activation of mid unit m is a sum
+// over the window rows of (sum over kw of w[m][kh][kw] x[kh][kw]), and a row has only KW <= 6 bits, so
+// that inner sum is a 2^KW-entry float64 table per (m, kh) (at most 20 KiB per channel, built in
+// LDS by the workgroup): KH lookups and adds per mid unit instead of KH*KW conditional adds.  (The
+// taps of a row are summed kw-ascending, the rows kh-ascending: another association than the
+// oracle's single running sum, a 1e-16 relative effect.)
+template <int KH, int KW>
+__global__ __launch_bounds__(256) void full_dw_tab_kernel(FullDwArgs a) {
+  __shared__ double tab[8][KH][1 << KW];
+  __shared__ double s1[8], t1[8], w2[8], s2, t2;
+  const int c = blockIdx.x;
+  constexpr int nk = KH * KW;
+  for (int i = threadIdx.x; i < 8 * KH * (1 << KW); i += blockDim.x) {
+    const int bits = i & ((1 << KW) - 1), kh = (i >> KW) % KH, m = i / (KH << KW);
+    double sum = 0.0;
+#pragma unroll
+    for (int kw = 0; kw < KW; ++kw) sum += ((bits >> kw) & 1) ? (double)a.w1[(size_t)c * 8 * nk + m * nk + kh * KW + kw] : 0.0;
+    tab[m][kh][bits] = sum;
+  }
+  if (threadIdx.x < 8) {
+    s1[threadIdx.x] = a.s1[c * 8 + threadIdx.x];
+    t1[threadIdx.x] = a.t1[c * 8 + threadIdx.x];
+    w2[threadIdx.x] = (double)a.w2[c * 8 + threadIdx.x];
+  }
+  if (threadIdx.x == 0) {
+    s2 = a.s2[c];
+    t2 = a.t2[c];
+  }
+  __syncthreads();
+  const int rows = a.n * a.ho;
+  for (int t = blockIdx.y * blockDim.x + threadIdx.x; t < rows; t += gridDim.y * blockDim.x) {
+    const int n = t / a.ho, oy = t % a.ho;
+    uint64_t r[KH];
+#pragma unroll
+    for (int kh = 0; kh < KH; ++kh) {
+      const int iy = oy * a.stride - a.pad + kh;
+      r[kh] = (iy >= 0 && iy < a.H) ? a.x_rp[((size_t)n * a.C + c) * a.H + iy] << a.pad : 0ull;   // bit 0 = column -pad
+    }
+    uint64_t out = 0;
+    for (int ox = 0; ox < a.wo; ++ox) {
+      uint32_t idx[KH];
+#pragma unroll
+      for (int kh = 0; kh < KH; ++kh) idx[kh] = (uint32_t)(r[kh] >> (ox * a.stride)) & ((1u << KW) - 1u);
+      double acc = 0.0;
+#pragma unroll
+      for (int m = 0; m < 8; ++m) {
+        double sm = tab[m][0][idx[0]];
+#pragma unroll
+        for (int kh = 1; kh < KH; ++kh) sm += tab[m][kh][idx[kh]];
+        acc = fma(gelu_exact(sm * s1[m] + t1[m]), w2[m], acc);
+      }
+      const double pre = acc * s2 + t2;
+      out |= (uint64_t)(pre >= 0.0) << (ox + a.pad_l);
+    }
+    a.out[((size_t)n * a.C + c) * a.Ho + oy + a.pad_t] = out;
+  }
+}
+
 // ---- grouped 1x1 Block_TT with `cin` inputs per group ------------------------------------------
 // Input bit (group g, j): channel J = cin*g + j of either a plane tensor (conv3) or of the
 // interleaved concat of four branch tensors (convf: channel J -> branch J%4, channel J/4;
@@ -356,7 +414,9 @@ int launch_full_dw(const FullDwArgs &a, hipStream_t s) {
   }
   const int rows = a.n * a.ho;
   const int chunks = std::max(1, std::min((rows + 255) / 256, std::max(1, 1024 / a.C)));
-  hipLaunchKernelGGL(full_dw_kernel, dim3(a.C, chunks), dim3(256), 0, s, a);
+  if (a.kh == 6 && a.kw == 5) hipLaunchKernelGGL((full_dw_tab_kernel<6, 5>), dim3(a.C, chunks), dim3(256), 0, s, a);
+  else if (a.kh == 5 && a.kw == 6) hipLaunchKernelGGL((full_dw_tab_kernel<5, 6>), dim3(a.C, chunks), dim3(256), 0, s, a);
+  else hipLaunchKernelGGL(full_dw_kernel, dim3(a.C, chunks), dim3(256), 0, s, a);
   TT_HIP(hipGetLastError());
   return TTNET_OK;
 }
