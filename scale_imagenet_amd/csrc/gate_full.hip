@@ -125,7 +125,8 @@ __global__ __launch_bounds__(256) void full_dw_tab_kernel(FullDwArgs a) {
 // interleaved concat of four branch tensors (convf: channel J -> branch J%4, channel J/4;
 // models/TT_general_imagenet_v2.py:131-135).  One wave = one image row; lanes = columns.
 // Output: bits (ballot -> row words) or, for the last block, relu'd float32.
-// 1024 threads share one copy of the group's weights in LDS (119 KiB for 30 -> 240 -> 30): sixteen
+// Generic version (any group shape that fits; the full model's 30 -> 240 -> 30 / 15 groups take the
+// matrix-instruction kernel below).  1024 threads share one copy of the group's weights in LDS (119 KiB for 30 -> 240 -> 30): sixteen
 // waves per CU hide the latency of the broadcast LDS reads that one wave per SIMD exposed (3x).
 // (Compile-time sizes with full unrolling were tried and were slower: more registers, same reads.)
 __global__ __launch_bounds__(1024) void full_pw_kernel(FullPwArgs a) {
@@ -187,68 +188,6 @@ __global__ __launch_bounds__(1024) void full_pw_kernel(FullPwArgs a) {
         const uint64_t m64 = __ballot(live && pre >= 0.0);
         if (live && x == 0)                               // the first lane of every row writes its row word
           a.out_rp[((size_t)n * a.Cout + g * cout + o) * a.H + y] = (m64 >> (r * a.W)) & ((1ull << a.W) - 1ull);
-      }
-    }
-  }
-}
-
-// The same block with the weights in SGPRs.  Every lane of a wave needs the same weight at the same
-// time, so the float64 record of hidden unit m ([30 input weights][COUT output weights], a.wd) is
-// fetched with scalar loads (wave-uniform address) instead of one LDS broadcast read per weight and
-// lane -- the LDS version is bound by the LDS instruction rate (14,400 reads per task).  The input
-// bits are expanded once per task to 0.0 / 1.0, so that layer 1 is an fma per input (w * 1 + s and
-// w * 0 + s round like the conditional add; same order, j ascending).  No LDS at all.
-template <int COUT>
-__global__ __launch_bounds__(256) void full_pw_sgpr_kernel(FullPwArgs a) {
-  constexpr int CIN = 30;
-  const int g = blockIdx.x, mid = a.mid;
-  const double *__restrict__ wg = a.wd + (size_t)g * mid * (CIN + COUT);
-  const double *__restrict__ s1 = a.s1 + (size_t)g * mid, *__restrict__ t1 = a.t1 + (size_t)g * mid;
-  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nwaves = blockDim.x >> 6;
-  const int rpw = 64 / a.W, bundles = (a.H + rpw - 1) / rpw;
-  const int r = lane / a.W, x = lane - r * a.W;
-  const int tasks = a.n * bundles;
-  for (int t = blockIdx.y * nwaves + wave; t < tasks; t += gridDim.y * nwaves) {
-    const int n = t / bundles, y = (t % bundles) * rpw + r;
-    const bool live = r < rpw && y < a.H;
-    double xb[CIN];
-#pragma unroll
-    for (int j = 0; j < CIN; ++j) {
-      const int J = CIN * g + j;
-      uint64_t row = 0;
-      if (live) row = a.interleaved ? a.src[J & 3][((size_t)n * a.Csrc + (J >> 2)) * a.H + y] : a.src[0][((size_t)n * a.Csrc + J) * a.H + y];
-      xb[j] = ((row >> x) & 1ull) ? 1.0 : 0.0;
-    }
-    double acc[COUT];
-#pragma unroll
-    for (int o = 0; o < COUT; ++o) acc[o] = 0.0;
-    for (int m = 0; m < mid; ++m) {
-      const double *__restrict__ rec = wg + (size_t)m * (CIN + COUT);       // wave-uniform: scalar loads
-      // (chunks of 10 weights: 20 SGPRs live at a time; the whole 60-weight record at once spills SGPRs)
-      double s = 0.0;
-      static_for<0, CIN / 10>([&](auto cc) {
-        constexpr int J0 = decltype(cc)::value * 10;
-#pragma unroll
-        for (int j = J0; j < J0 + 10; ++j) s = fma(rec[j], xb[j], s);
-        __builtin_amdgcn_sched_barrier(0);
-      });
-      const double h = gelu_exact(s * s1[m] + t1[m]);
-      static_for<0, (COUT + 9) / 10>([&](auto cc) {
-        constexpr int O0 = decltype(cc)::value * 10, O1 = O0 + 10 < COUT ? O0 + 10 : COUT;
-#pragma unroll
-        for (int o = O0; o < O1; ++o) acc[o] = fma(h, rec[CIN + o], acc[o]);
-        __builtin_amdgcn_sched_barrier(0);
-      });
-    }
-#pragma unroll
-    for (int o = 0; o < COUT; ++o) {
-      const double pre = acc[o] * a.s2[g * COUT + o] + a.t2[g * COUT + o];
-      if (a.out_float) {
-        if (live) a.out_float[(((size_t)n * a.Cout + g * COUT + o) * a.H + y) * a.W + x] = (float)(pre > 0.0 ? pre : 0.0);
-      } else {
-        const uint64_t m64 = __ballot(live && pre >= 0.0);
-        if (live && x == 0)
-          a.out_rp[((size_t)n * a.Cout + g * COUT + o) * a.H + y] = (m64 >> (r * a.W)) & ((1ull << a.W) - 1ull);
       }
     }
   }
@@ -422,7 +361,7 @@ int launch_full_dw(const FullDwArgs &a, hipStream_t s) {
 }
 
 int launch_full_pw(const FullPwArgs &a, hipStream_t s) {
-  if (a.cin == 30 && a.mid == 240 && (a.cout == 30 || a.cout == 15) && a.W <= 64 && !getenv("TTNET_FULL_NO_MFMA")) {
+  if (a.cin == 30 && a.mid == 240 && (a.cout == 30 || a.cout == 15) && a.W <= 64) {
     const int ot = a.cout == 30 ? 2 : 1;
     const size_t lds = sizeof(double) * ((size_t)15 * 8 * 64 + (size_t)15 * 4 * ot * 64 + 2 * 240);
     const int rpw = 64 / a.W, tasks = a.n * ((a.H + rpw - 1) / rpw);
@@ -434,14 +373,6 @@ int launch_full_pw(const FullPwArgs &a, hipStream_t s) {
       TT_TRY(ensure_dynamic_lds((const void *)full_pw_mfma_kernel<1>, lds));
       hipLaunchKernelGGL(full_pw_mfma_kernel<1>, dim3(a.groups, chunks), dim3(512), lds, s, a);
     }
-    TT_HIP(hipGetLastError());
-    return TTNET_OK;
-  }
-  if (a.wd && a.cin == 30 && (a.cout == 30 || a.cout == 15) && a.W <= 64) {
-    const int rpw = 64 / a.W, tasks = a.n * ((a.H + rpw - 1) / rpw);
-    const int chunks = std::max(1, std::min((tasks + 3) / 4, std::max(1, 2048 / a.groups)));
-    if (a.cout == 30) hipLaunchKernelGGL(full_pw_sgpr_kernel<30>, dim3(a.groups, chunks), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL(full_pw_sgpr_kernel<15>, dim3(a.groups, chunks), dim3(256), 0, s, a);
     TT_HIP(hipGetLastError());
     return TTNET_OK;
   }

@@ -54,8 +54,6 @@ struct BlockTT {
   std::vector<uint8_t> perm;     // internal index bit p -> canonical input column
   uint8_t *perm_dev = nullptr;
   double *s1 = nullptr, *t1 = nullptr, *s2 = nullptr, *t2 = nullptr;
-  double *wd = nullptr;          // full variant, grouped 1x1 blocks: [groups][mid][cin + cout] float64 weights
-                                 // (hidden unit m: its cin input weights, then its cout output weights)
   void *table = nullptr;         // internal layout
   unsigned *near_dev = nullptr;
   int64_t near_ties = -1;
@@ -528,8 +526,6 @@ int allocate(ttnet_plan *pl) {
       TT_TRY(dev_alloc(pl, &b->s2, g.out_planes, false));
       TT_TRY(dev_alloc(pl, &b->t2, g.out_planes, false));
       TT_TRY(dev_alloc(pl, &b->near_dev, 1, true));
-      if (pl->full && g.kh == 1 && g.kw == 1)
-        TT_TRY(dev_alloc(pl, &b->wd, (size_t)g.groups * g.mid_g() * (g.cin_g() + g.cout_g()), false));
     }
   }
   TT_TRY(dev_alloc(pl, &pl->w1f, frag_elems(pl->va ? 128 : (pl->inter + 127) / 128 * 128, pl->fcsize), false));
@@ -580,22 +576,6 @@ int build_table(ttnet_plan *pl, BlockTT &b, hipStream_t s) {
   TT_HIP(hipMemcpy(b.t1, t1.data(), t1.size() * 8, hipMemcpyHostToDevice));
   TT_HIP(hipMemcpy(b.s2, s2.data(), s2.size() * 8, hipMemcpyHostToDevice));
   TT_HIP(hipMemcpy(b.t2, t2.data(), t2.size() * 8, hipMemcpyHostToDevice));
-  if (pl->full && b.wd) {
-    // float64 copies of the grouped 1x1 weights, one contiguous record per hidden unit: the
-    // pointwise kernel reads them with scalar loads (wave-uniform addresses)
-    std::vector<float> w1, w2;
-    TT_TRY(fetch(pl->tensors[b.g.name + ".conv1.weight"], w1));
-    TT_TRY(fetch(pl->tensors[b.g.name + ".conv2.weight"], w2));
-    const int G = b.g.groups, mid = b.g.mid_g(), cin = b.g.cin_g(), cout = b.g.cout_g();
-    std::vector<double> wd((size_t)G * mid * (cin + cout));
-    for (int g = 0; g < G; ++g)
-      for (int m = 0; m < mid; ++m) {
-        double *rec = &wd[((size_t)g * mid + m) * (cin + cout)];
-        for (int j = 0; j < cin; ++j) rec[j] = (double)w1[((size_t)g * mid + m) * cin + j];
-        for (int o = 0; o < cout; ++o) rec[cin + o] = (double)w2[((size_t)g * cout + o) * mid + m];
-      }
-    TT_HIP(hipMemcpy(b.wd, wd.data(), wd.size() * 8, hipMemcpyHostToDevice));
-  }
   if (b.user_table || pl->full) return TTNET_OK;
   TT_HIP(hipMemsetAsync(b.near_dev, 0, sizeof(unsigned), s));
   LutBuildArgs a{};
@@ -679,7 +659,7 @@ int run_full_block(ttnet_plan *pl, size_t i, int n, hipStream_t s) {
     a.groups = b.g.groups; a.cin = b.g.cin_g(); a.mid = b.g.mid_g(); a.cout = b.g.cout_g(); a.Cout = b.g.out_planes;
     a.Csrc = mh.C; a.interleaved = 0; a.src[0] = pl->x_rp[i];
     a.w1 = wts(b, ".conv1.weight"); a.w2 = wts(b, ".conv2.weight");
-    a.s1 = b.s1; a.t1 = b.t1; a.s2 = b.s2; a.t2 = b.t2; a.wd = b.wd;
+    a.s1 = b.s1; a.t1 = b.t1; a.s2 = b.s2; a.t2 = b.t2;
     a.out_rp = mh.c3_tmp; a.out_float = nullptr;
     static const char *const kC3[4] = {"full.conv3.f4", "full.conv3.f5", "full.conv3.f6", "full.conv3.f7"};
     TT_TIMED(pl, kC3[std::min<size_t>(i, 3)], s, launch_full_pw(a, s));
@@ -696,7 +676,7 @@ int run_full_block(ttnet_plan *pl, size_t i, int n, hipStream_t s) {
     a.Csrc = mh.C; a.interleaved = 1;
     for (int k = 0; k < 4; ++k) a.src[k] = o64[k];
     a.w1 = wts(b, ".conv1.weight"); a.w2 = wts(b, ".conv2.weight");
-    a.s1 = b.s1; a.t1 = b.t1; a.s2 = b.s2; a.t2 = b.t2; a.wd = b.wd;
+    a.s1 = b.s1; a.t1 = b.t1; a.s2 = b.s2; a.t2 = b.t2;
     if (mh.last) {
       a.out_rp = nullptr; a.out_float = pl->last_float;
       TT_TIMED(pl, "full.convf_last", s, launch_full_pw(a, s));

@@ -227,7 +227,6 @@ struct FullPwArgs {
   int interleaved;          // 0: src[0] planes; 1: channel J -> src[J%4] plane J/4 (the 4-branch concat)
   const uint64_t *src[4];
   const float *w1, *w2;     // conv1.weight [G*mid][cin], conv2.weight [G*cout][mid]
-  const double *wd;         // the same in float64, [G][mid][cin + cout]: unit m's input then output weights
   const double *s1, *t1, *s2, *t2;
   uint64_t *out_rp;         // [n][Cout][H]  (binarised blocks)
   float *out_float;         // [n][Cout][H][W] relu'd (last block), or nullptr
