@@ -522,29 +522,42 @@ __global__ __launch_bounds__(256) void gate_last_kernel(GateBlockArgs a, const f
   store_feature(feat_frag, n, G * PP, g * PP + pp, k, f);
 }
 
-// The same for the 8x8 -> 4x4 geometry of the default network: one workgroup per (group, image),
-// thread = (pooled pixel, k).  The 64 table indices of the 8x8 plane are formed once by the
-// first wave and shared through LDS; what is left per thread is four 64-byte-row gathers.
+// The same for the 8x8 -> 4x4 geometry of the default network: one workgroup per (channel word,
+// image), thread = (pooled pixel, k).  The table indices of the 8x8 plane are formed once and
+// shared through LDS; what is left per thread is the 64-byte-row gathers.
 // (The generic kernel above spends ~220 VALU instructions per wave on index arithmetic and is
 // VALU bound: 28 us at B = 256.)
 __global__ __launch_bounds__(256) void gate_last8_kernel(GateBlockArgs a, const float *__restrict__ t_last,
                                                          uint16_t *__restrict__ feat_frag) {
-  __shared__ uint32_t s_off[64];
-  const int g = blockIdx.x, n = blockIdx.y, G = gridDim.x, Q = a.C / 16;
-  if (threadIdx.x < 64) {
-    const size_t pix = ((size_t)n * Q + (g >> 2)) * 64 + threadIdx.x;
-    const int sh = 4 * (g & 3);
+  // one workgroup = the four groups that share a channel word (g = 4 wq + s) of one image: wave s
+  // forms the 64 table indices of group s (one pixel per lane), then every thread (pooled pixel, k)
+  // gathers its four rows for each of the four groups -- sixteen 64-byte-row reads in flight
+  __shared__ uint32_t s_off[4][64];
+  const int wq = blockIdx.x, n = blockIdx.y, G = 4 * gridDim.x, Q = a.C / 16;
+  {
+    const int sgrp = threadIdx.x >> 6, pixl = threadIdx.x & 63, sh = 4 * sgrp;
+    const size_t pix = ((size_t)n * Q + wq) * 64 + pixl;
     const uint32_t idx = ((a.o1[pix] >> sh) & 15) | (((a.o2[pix] >> sh) & 15) << 4) | (((a.o3[pix] >> sh) & 15) << 8) |
                          (((a.o4[pix] >> sh) & 15) << 12);
-    s_off[threadIdx.x] = idx * 16;
+    s_off[sgrp][pixl] = idx * 16;
   }
   __syncthreads();
   const int k = threadIdx.x & 15, pp = threadIdx.x >> 4;
   const int p00 = 16 * (pp >> 2) + 2 * (pp & 3);            // pixel (2py, 2px) of the 8x8 plane
-  const float *tab = t_last + (size_t)g * 65536 * 16 + k;
-  const float v0 = tab[s_off[p00]], v1 = tab[s_off[p00 + 1]], v2 = tab[s_off[p00 + 8]], v3 = tab[s_off[p00 + 9]];
-  const float f = (((v0 + v1) + v2) + v3) * 0.25f;
-  store_feature(feat_frag, n, G * 16, g * 16 + pp, k, f);
+  float v[4][4];
+#pragma unroll
+  for (int sgrp = 0; sgrp < 4; ++sgrp) {
+    const float *tab = t_last + (size_t)(4 * wq + sgrp) * 65536 * 16 + k;
+    v[sgrp][0] = tab[s_off[sgrp][p00]];
+    v[sgrp][1] = tab[s_off[sgrp][p00 + 1]];
+    v[sgrp][2] = tab[s_off[sgrp][p00 + 8]];
+    v[sgrp][3] = tab[s_off[sgrp][p00 + 9]];
+  }
+#pragma unroll
+  for (int sgrp = 0; sgrp < 4; ++sgrp) {
+    const float f = (((v[sgrp][0] + v[sgrp][1]) + v[sgrp][2]) + v[sgrp][3]) * 0.25f;
+    store_feature(feat_frag, n, G * 16, (4 * wq + sgrp) * 16 + pp, k, f);
+  }
 }
 
 // ---- layout conversions (parity taps and ttnet_forward_from_stem_bits only) -----------------
@@ -662,7 +675,7 @@ int launch_gate_pf(const GateBlockArgs &a, const uint8_t *t_cf, uint16_t *out_cp
 
 int launch_gate_last(const GateBlockArgs &a, const float *t_last, void *feat_frag, hipStream_t s) {
   if (a.Ho == 8 && a.Wo == 8 && a.n <= 65535) {
-    hipLaunchKernelGGL(gate_last8_kernel, dim3(a.C / 4, a.n), dim3(256), 0, s, a, t_last, (uint16_t *)feat_frag);
+    hipLaunchKernelGGL(gate_last8_kernel, dim3(a.C / 16, a.n), dim3(256), 0, s, a, t_last, (uint16_t *)feat_frag);
     TT_HIP(hipGetLastError());
     return TTNET_OK;
   }
