@@ -137,16 +137,17 @@ __global__ __launch_bounds__(64 * G_WAVES) void gemm_f16x2_kernel(const uint8_t 
 #pragma unroll
         for (int pl = 0; pl < NP; ++pl)
           b[j][pl] = *(const f16x8 *)(st + ((G_MT * G_KS * NP + (j * G_KS + kk) * NP + pl) * G_CHUNK) + lane * 16);
+      // the three products of a tile go to the same accumulator: issue them tile-interleaved, so that
+      // consecutive MFMAs are independent (same per-accumulator order: low terms first)
 #pragma unroll
-      for (int i = 0; i < MPW; ++i)
+      for (int i = 0; i < MPW; ++i) {
 #pragma unroll
-        for (int j = 0; j < G_NT; ++j) {
-          f32x16 c = acc[i][j];
-          c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][1], b[j][0], c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][0], b[j][1], c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][0], b[j][0], c, 0, 0, 0);
-          acc[i][j] = c;
-        }
+        for (int j = 0; j < G_NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][1], b[j][0], acc[i][j], 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < G_NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][0], b[j][1], acc[i][j], 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < G_NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][0], b[j][0], acc[i][j], 0, 0, 0);
+      }
     }
   }
   // C/D layout: col = lane&31 (N), row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) (M)
