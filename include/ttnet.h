@@ -44,7 +44,8 @@ typedef enum ttnet_status {
   TTNET_E_STATE = -2,        /* call out of order (forward before finalize, missing tensor) */
   TTNET_E_HIP = -3,          /* a HIP runtime call failed; message carries hipGetErrorString */
   TTNET_E_UNSUPPORTED = -4,  /* geometry this build has no kernel for */
-  TTNET_E_NOMEM = -5
+  TTNET_E_NOMEM = -5,
+  TTNET_E_RANGE = -6         /* an earlier forward met a value outside the fp16 x 2 operand split (see ttnet_forward) */
 } ttnet_status;
 
 typedef enum ttnet_dtype { TTNET_F32 = 0, TTNET_I64 = 1, TTNET_U8 = 2, TTNET_U16 = 3, TTNET_U64 = 4 } ttnet_dtype;
@@ -99,7 +100,15 @@ int ttnet_plan_finalize(ttnet_plan *plan, void *stream);
  *   logits_dev float32 [n,n_classes]  (1000; 10 for TTNET_VALEXNET)
  * Asynchronous on `stream`.  From the third call with the same n the launches are replayed from a
  * hipGraph captured on a private stream (the input / logits pointers are patched per call);
- * TTNET_NO_GRAPH=1 in the environment keeps plain launches.  Results are identical either way. */
+ * TTNET_NO_GRAPH=1 in the environment keeps plain launches.  Results are identical either way.
+ * Setting a tensor, a table or finalizing drops every captured graph (they are re-captured).
+ * Range.  The float stages run on the 16-bit matrix cores with every float32 operand carried as two
+ * fp16 terms after a power-of-two prescale (x16 for activations): inputs, pooled features and
+ * classifier activations must satisfy |v| < 4094 (the reference's float32 path has no such limit;
+ * normalised ImageNet inputs span [-2.2, 2.7]).  A value outside the range, or a NaN, raises a sticky
+ * flag from inside the kernel; since the forward is asynchronous, it is the NEXT call on the plan
+ * (forward, read_stage) that fails with TTNET_E_RANGE, and keeps failing until
+ * ttnet_plan_query("range_overflow") has read and cleared the flag. */
 int ttnet_forward(ttnet_plan *plan, const float *x_dev, int64_t n, float *logits_dev, void *stream);
 
 /* Batches in flight.  A plan starts with one lane = one set of activation buffers; lanes share
@@ -149,7 +158,9 @@ int ttnet_plan_set_table(ttnet_plan *plan, const char *name, const void *src_hos
 /* Integer facts about the plan: "fcsize", "n_classes", "n_state_tensors", "max_batch",
  * "near_ties:<block_tt name>" (entries with |pre-activation| < 1e-5 found while building
  * that table), "table_bytes", "workspace_bytes", "graph_replays" (forwards replayed from a
- * captured hipGraph so far), "graphs_enabled", "lanes". */
+ * captured hipGraph so far), "graphs_enabled" (0: ttnet_last_error() then says why), "graph_captures",
+ * "graph_drops", "graphs_cached", "lanes", "range_overflow" (synchronises; 1 if a forward since the last
+ * query left the fp16 x 2 range, and clears the flag). */
 int ttnet_plan_query(ttnet_plan *plan, const char *what, int64_t *out);
 
 /* Device time of the kernels of the last forward, measured with HIP events on the stream

@@ -14,6 +14,8 @@ into the reference's own model classes and records what the REFERENCE computes:
                                              models/TT_FHE_SMALL.py:322-342) and the list
                                              of entries where it differs from the float64
                                              oracle table (must all be near ties)
+  tests/golden/ref_spread.json               the reference's own logit spread (threads, batch split)
+                                             and its distance from the float64 head (gen_spread)
   scale_imagenet_amd/data/synth_head_bn_<variant>.npz
                                              calibrated BatchNorm1d statistics of the
                                              synthetic classifier (data, see synth.py)
@@ -321,6 +323,47 @@ def gen_depth_golden(layers: int, n: int = 2):
           f"shapes {[tuple(ref_taps[b.name].shape[1:]) for b in spec.blocks]}")
 
 
+def gen_spread(variants=("small", "xsmall", "full")):
+    """tests/golden/ref_spread.json: how far the REFERENCE's own float32 logits move with things that
+    are not part of its definition -- its intra-op thread count and the batch split -- and how far
+    they sit from the float64 evaluation of the same head on the reference's own features.  This is
+    the committed justification of the parity tests' allowance next to the north star's 1e-5:
+    |hip - reference| <= 1e-5 + ref_vs_exact[variant]."""
+    out = {"torch": torch.__version__, "variants": {}}
+    for variant in variants:
+        spec = make_spec(variant, **VARIANT_ARGS[variant])
+        m = import_reference(variant)
+        st = synth.synth_state_dict(spec)
+        m.load_state_dict(OF.to_torch_state(st), strict=True)
+        n = BATCH[variant]
+        x = torch.from_numpy(synth.synth_images(n, hw=spec.image_hw))
+        flat = {}
+        h = m.features[4 + len(spec.blocks) + 1].register_forward_hook(lambda mod, i, o: flat.__setitem__("f", o.detach().clone()))
+        with torch.no_grad():
+            torch.set_num_threads(8)
+            y8 = m(x).clone()
+            ysplit = torch.cat([m(x[: n // 2]), m(x[n // 2:])])
+            m(x)
+            torch.set_num_threads(1)
+            y1 = m(x).clone()
+            torch.set_num_threads(8)
+        h.remove()
+        exact = OB.head64(flat["f"].numpy(), st, f"features.{4 + len(spec.blocks) + 2}")
+        with np.load(os.path.join(GOLD, f"ref_{variant}.npz")) as z:
+            assert np.array_equal(z["logits"], y8.numpy()), "the committed logits are the 8-thread full-batch run"
+        out["variants"][variant] = {
+            "images": n,
+            "logit_abs_max": float(y8.abs().max()),
+            "ref_vs_exact": float(np.abs(y8.numpy() - exact).max()),
+            "threads_1_vs_8": float((y1 - y8).abs().max()),
+            "split_vs_full": float((ysplit - y8).abs().max()),
+            "threads_1_vs_exact": float(np.abs(y1.numpy() - exact).max()),
+        }
+        print(f"[spread {variant}]", out["variants"][variant])
+    with open(os.path.join(GOLD, "ref_spread.json"), "w") as f:
+        json.dump(out, f, indent=1)
+
+
 def main(variants):
     os.makedirs(GOLD, exist_ok=True)
     torch.set_num_threads(8)
@@ -443,6 +486,8 @@ def main(variants):
 if __name__ == "__main__":
     if sys.argv[1:] == ["export"]:
         gen_export_golden()
+    elif sys.argv[1:] == ["spread"]:
+        gen_spread()
     elif sys.argv[1:2] == ["depth"]:
         for L in [int(a) for a in sys.argv[2:]] or [3, 4]:
             gen_depth_golden(L)
@@ -451,3 +496,4 @@ if __name__ == "__main__":
         gen_export_golden()
         for L in (3, 4):
             gen_depth_golden(L)
+        gen_spread()

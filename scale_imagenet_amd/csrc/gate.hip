@@ -138,7 +138,7 @@ __device__ inline uint32_t dw_row_4x4s2(const uint64_t (&rows)[4], const uint32_
     constexpr int I = decltype(i)::value;
     const uint32_t partner = (uint32_t)__builtin_amdgcn_ds_swizzle((int)acc, 0x1F | (S[I] << 10));
     const uint32_t moved = __builtin_amdgcn_alignbit(partner, partner, k.rot[I]);
-    acc = (acc & k.keep[I]) | (moved & ~k.keep[I]);
+    acc = moved ^ ((moved ^ acc) & k.keep[I]);
   });
   return acc;
 }
@@ -498,7 +498,14 @@ __global__ __launch_bounds__(kGateThreads) void gate_pf_kernel(GateBlockArgs a, 
 // row; the table for all 64 groups is 256 MiB and sits in HBM / Infinity Cache.  The
 // following AvgPool2d(2) (:197) is fused: four rows are gathered and averaged.
 // 16 lanes share one (image, group, pooled pixel) and read one 64-byte row together.
-__global__ __launch_bounds__(256) void gate_last_kernel(GateBlockArgs a, const float *t_last, uint16_t *feat_frag) {
+// table index of Block_convf group g at a pixel from the branch dword of gate_fused.hip (strand g >> 1:
+// bytes (0,2) are the index of its even group, bytes (1,3) of its odd group)
+__device__ inline uint32_t last_index_from_dword(uint32_t d, int g) {
+  return __builtin_amdgcn_perm(0u, d, (g & 1) ? 0x0C0C0301u : 0x0C0C0200u);
+}
+
+__global__ __launch_bounds__(256) void gate_last_kernel(GateBlockArgs a, const float *t_last, uint16_t *feat_frag,
+                                                        uint32_t *range_flag, const uint32_t *__restrict__ bidx) {
   const int Q = a.C / 16, G = a.C / 4;
   const int Hp = a.Ho / 2, Wp = a.Wo / 2, PP = Hp * Wp;
   const size_t task = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
@@ -512,14 +519,19 @@ __global__ __launch_bounds__(256) void gate_last_kernel(GateBlockArgs a, const f
   float v[4];
 #pragma unroll
   for (int d = 0; d < 4; ++d) {
-    const size_t pix = (((size_t)n * Q + wq) * a.Ho + 2 * py + (d >> 1)) * a.Wo + 2 * px + (d & 1);
-    const uint32_t idx = ((a.o1[pix] >> sh) & 15) | (((a.o2[pix] >> sh) & 15) << 4) |
-                         (((a.o3[pix] >> sh) & 15) << 8) | (((a.o4[pix] >> sh) & 15) << 12);
+    uint32_t idx;
+    if (bidx) {
+      idx = last_index_from_dword(bidx[((size_t)n * (a.C / 8) + (g >> 1)) * a.Ho * a.Wo + (2 * py + (d >> 1)) * a.Wo + 2 * px + (d & 1)], g);
+    } else {
+      const size_t pix = (((size_t)n * Q + wq) * a.Ho + 2 * py + (d >> 1)) * a.Wo + 2 * px + (d & 1);
+      idx = ((a.o1[pix] >> sh) & 15) | (((a.o2[pix] >> sh) & 15) << 4) | (((a.o3[pix] >> sh) & 15) << 8) |
+            (((a.o4[pix] >> sh) & 15) << 12);
+    }
     v[d] = tab[(size_t)idx * 16 + k];
   }
   const float f = (((v[0] + v[1]) + v[2]) + v[3]) * 0.25f;
   // fp16 x 2 split, stored where lin1's MFMA fragments expect it: row = image, k-step = g*PP + pp, k
-  store_feature(feat_frag, n, G * PP, g * PP + pp, k, f);
+  store_feature(feat_frag, n, G * PP, g * PP + pp, k, f, range_flag);
 }
 
 // The same for the 8x8 -> 4x4 geometry of the default network: one workgroup per (channel word,
@@ -528,7 +540,8 @@ __global__ __launch_bounds__(256) void gate_last_kernel(GateBlockArgs a, const f
 // (The generic kernel above spends ~220 VALU instructions per wave on index arithmetic and is
 // VALU bound: 28 us at B = 256.)
 __global__ __launch_bounds__(256) void gate_last8_kernel(GateBlockArgs a, const float *__restrict__ t_last,
-                                                         uint16_t *__restrict__ feat_frag) {
+                                                         uint16_t *__restrict__ feat_frag, uint32_t *range_flag,
+                                                         const uint32_t *__restrict__ bidx) {
   // one workgroup = the four groups that share a channel word (g = 4 wq + s) of one image: wave s
   // forms the 64 table indices of group s (one pixel per lane), then every thread (pooled pixel, k)
   // gathers its four rows for each of the four groups -- sixteen 64-byte-row reads in flight
@@ -536,9 +549,14 @@ __global__ __launch_bounds__(256) void gate_last8_kernel(GateBlockArgs a, const 
   const int wq = blockIdx.x, n = blockIdx.y, G = 4 * gridDim.x, Q = a.C / 16;
   {
     const int sgrp = threadIdx.x >> 6, pixl = threadIdx.x & 63, sh = 4 * sgrp;
-    const size_t pix = ((size_t)n * Q + wq) * 64 + pixl;
-    const uint32_t idx = ((a.o1[pix] >> sh) & 15) | (((a.o2[pix] >> sh) & 15) << 4) | (((a.o3[pix] >> sh) & 15) << 8) |
-                         (((a.o4[pix] >> sh) & 15) << 12);
+    uint32_t idx;
+    if (bidx) {
+      idx = last_index_from_dword(bidx[((size_t)n * (2 * Q) + 2 * wq + (sgrp >> 1)) * 64 + pixl], sgrp);
+    } else {
+      const size_t pix = ((size_t)n * Q + wq) * 64 + pixl;
+      idx = ((a.o1[pix] >> sh) & 15) | (((a.o2[pix] >> sh) & 15) << 4) | (((a.o3[pix] >> sh) & 15) << 8) |
+            (((a.o4[pix] >> sh) & 15) << 12);
+    }
     s_off[sgrp][pixl] = idx * 16;
   }
   __syncthreads();
@@ -556,7 +574,7 @@ __global__ __launch_bounds__(256) void gate_last8_kernel(GateBlockArgs a, const 
 #pragma unroll
   for (int sgrp = 0; sgrp < 4; ++sgrp) {
     const float f = (((v[sgrp][0] + v[sgrp][1]) + v[sgrp][2]) + v[sgrp][3]) * 0.25f;
-    store_feature(feat_frag, n, G * 16, (4 * wq + sgrp) * 16 + pp, k, f);
+    store_feature(feat_frag, n, G * 16, (4 * wq + sgrp) * 16 + pp, k, f, range_flag);
   }
 }
 
@@ -673,15 +691,17 @@ int launch_gate_pf(const GateBlockArgs &a, const uint8_t *t_cf, uint16_t *out_cp
   return TTNET_E_UNSUPPORTED;
 }
 
-int launch_gate_last(const GateBlockArgs &a, const float *t_last, void *feat_frag, hipStream_t s) {
+int launch_gate_last(const GateBlockArgs &a, const float *t_last, void *feat_frag, uint32_t *range_flag, hipStream_t s,
+                     const uint32_t *idx) {
   if (a.Ho == 8 && a.Wo == 8 && a.n <= 65535) {
-    hipLaunchKernelGGL(gate_last8_kernel, dim3(a.C / 16, a.n), dim3(256), 0, s, a, t_last, (uint16_t *)feat_frag);
+    hipLaunchKernelGGL(gate_last8_kernel, dim3(a.C / 16, a.n), dim3(256), 0, s, a, t_last, (uint16_t *)feat_frag, range_flag, idx);
     TT_HIP(hipGetLastError());
     return TTNET_OK;
   }
   const size_t tasks = (size_t)a.n * (a.C / 4) * (a.Ho / 2) * (a.Wo / 2);
   const size_t threads = tasks * 16;
-  hipLaunchKernelGGL(gate_last_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, a, t_last, (uint16_t *)feat_frag);
+  hipLaunchKernelGGL(gate_last_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, a, t_last, (uint16_t *)feat_frag,
+                     range_flag, idx);
   TT_HIP(hipGetLastError());
   return TTNET_OK;
 }

@@ -333,7 +333,7 @@ __global__ void rp_majority_kernel(const uint64_t *x, uint64_t *out, int n, int 
 
 // AvgPool2d(2) (floor) of the last block's float output + fp16 x 2 split into lin1's
 // fragment order (feature channel ch, pooled pixel pp: k-step (ch/16)*PP + pp, k = ch%16)
-__global__ void full_pool_split_kernel(const float *x, uint16_t *feat_frag, int n, int C, int H, int W) {
+__global__ void full_pool_split_kernel(const float *x, uint16_t *feat_frag, int n, int C, int H, int W, uint32_t *range_flag) {
   const int Hp = H / 2, Wp = W / 2, PP = Hp * Wp, KS = (C / 16) * PP;
   const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= (size_t)n * C * PP) return;
@@ -341,7 +341,7 @@ __global__ void full_pool_split_kernel(const float *x, uint16_t *feat_frag, int 
   const int py = pp / Wp, px = pp % Wp;
   const float *p = x + (((size_t)img * C + ch) * H + 2 * py) * W + 2 * px;
   const float f = (((p[0] + p[1]) + p[W]) + p[W + 1]) * 0.25f;
-  store_feature(feat_frag, img, KS, (ch / 16) * PP + pp, ch % 16, f);
+  store_feature(feat_frag, img, KS, (ch / 16) * PP + pp, ch % 16, f, range_flag);
 }
 
 }  // namespace
@@ -403,10 +403,10 @@ int launch_rp_majority(const uint64_t *x, uint64_t *out, int n, int C, int H, in
   return TTNET_OK;
 }
 
-int launch_full_pool_split(const float *x, void *feat_frag, int n, int C, int H, int W, hipStream_t s) {
+int launch_full_pool_split(const float *x, void *feat_frag, int n, int C, int H, int W, uint32_t *range_flag, hipStream_t s) {
   const size_t t = (size_t)n * C * (H / 2) * (W / 2);
   hipLaunchKernelGGL(full_pool_split_kernel, dim3((unsigned)((t + 255) / 256)), dim3(256), 0, s, x, (uint16_t *)feat_frag, n, C,
-                     H, W);
+                     H, W, range_flag);
   TT_HIP(hipGetLastError());
   return TTNET_OK;
 }

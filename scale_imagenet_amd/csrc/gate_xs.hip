@@ -123,7 +123,8 @@ __global__ void xs_pf_kernel(int n, int C, int Ho, int Wo, int cout_g, const uin
 // two fp16 planes in lin1's fragment order (feature channel ch, pooled pixel pp:
 // k-step = (ch/16)*PP + pp, k = ch%16) -- the same convention as gate_last_kernel.
 __global__ void xs_last_kernel(int n, int C, int Ho, int Wo, int cout_g, const uint64_t *o1, const uint64_t *o2,
-                               const uint64_t *o3, const uint64_t *o4, const float *t_last, uint16_t *feat_frag) {
+                               const uint64_t *o3, const uint64_t *o4, const float *t_last, uint16_t *feat_frag,
+                               uint32_t *range_flag) {
   const int Hp = Ho / 2, Wp = Wo / 2, PP = Hp * Wp;
   const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= (size_t)n * C * PP) return;
@@ -144,7 +145,7 @@ __global__ void xs_last_kernel(int n, int C, int Ho, int Wo, int cout_g, const u
   for (int k = 0; k < cout_g; ++k) {
     const int ch = c * cout_g + k;
     const float f = acc[k];
-    store_feature(feat_frag, img, KS, (ch / 16) * PP + pp, ch % 16, f);
+    store_feature(feat_frag, img, KS, (ch / 16) * PP + pp, ch % 16, f, range_flag);
   }
 }
 
@@ -176,14 +177,14 @@ int launch_xs_pf(int n, int C, int Ho, int Wo, int cout_g, uint64_t *const o[4],
 }
 
 int launch_xs_last(int n, int C, int Ho, int Wo, int cout_g, uint64_t *const o[4], const float *t_last, void *feat_frag,
-                   hipStream_t s) {
+                   uint32_t *range_flag, hipStream_t s) {
   if (cout_g > 8 || (C * cout_g) % 16) {
     set_error("xs_last: cout_g=%d", cout_g);
     return TTNET_E_UNSUPPORTED;
   }
   const size_t t = (size_t)n * C * (Ho / 2) * (Wo / 2);
   hipLaunchKernelGGL(xs_last_kernel, dim3((unsigned)((t + 127) / 128)), dim3(128), 0, s, n, C, Ho, Wo, cout_g, o[0], o[1], o[2],
-                     o[3], t_last, (uint16_t *)feat_frag);
+                     o[3], t_last, (uint16_t *)feat_frag, range_flag);
   TT_HIP(hipGetLastError());
   return TTNET_OK;
 }

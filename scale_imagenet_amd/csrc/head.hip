@@ -198,7 +198,7 @@ __global__ void frag_to_ref_kernel(const uint16_t *__restrict__ af, float *__res
 // (fragment order, KS2 = ceil(N/16) k-steps; the k padding stays zero from allocation)
 __global__ void head_mid_kernel(const float *__restrict__ part, int splits, const float *__restrict__ scale,
                                 const float *__restrict__ shift, uint16_t *__restrict__ mid_frag, int M, int N,
-                                int polynomial) {
+                                int polynomial, uint32_t *range_flag) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (size_t)M * N) return;
   const int nidx = i % N, row = i / N;
@@ -211,7 +211,7 @@ __global__ void head_mid_kernel(const float *__restrict__ part, int splits, cons
     const float t = __fadd_rn(0.47f, __fmul_rn(0.50f, y));
     y = __fadd_rn(t, __fmul_rn(0.09f, __fmul_rn(y, y)));
   }
-  store_feature(mid_frag, row, (N + 15) / 16, nidx >> 4, nidx & 15, y);
+  store_feature(mid_frag, row, (N + 15) / 16, nidx >> 4, nidx & 15, y, range_flag);
 }
 
 // ---- lin2: out[M][N] = A[M][K] * B[N][K]^T * inv + bias, split operands in fragment order ----
@@ -339,10 +339,10 @@ int launch_frag_to_reference_order(const void *af, float *out, int n, int G, int
 }
 
 int launch_head_mid(const float *part, int splits, const float *scale, const float *shift, void *mid_frag, int M, int N,
-                    int polynomial, hipStream_t s) {
+                    int polynomial, uint32_t *range_flag, hipStream_t s) {
   const size_t t = (size_t)M * N;
   hipLaunchKernelGGL(head_mid_kernel, dim3((unsigned)((t + 255) / 256)), dim3(256), 0, s, part, splits, scale, shift,
-                     (uint16_t *)mid_frag, M, N, polynomial);
+                     (uint16_t *)mid_frag, M, N, polynomial, range_flag);
   TT_HIP(hipGetLastError());
   return TTNET_OK;
 }

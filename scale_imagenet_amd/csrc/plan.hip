@@ -67,6 +67,9 @@ struct MultiHead {
   bool last = false;
   BlockTT c1, c2, c3, cf;
   uint16_t *o[4] = {nullptr, nullptr, nullptr, nullptr};
+  // block-fused path (gate_fused.hip): table images; the branch dwords of a last block
+  void *img_dw = nullptr, *img_c3 = nullptr;
+  uint32_t *idx = nullptr;
 };
 
 struct Timing {
@@ -104,6 +107,10 @@ struct ttnet_plan {
   bool xs = false;                  // x-small variant: row-packed branch tensors, gate_xs.hip kernels
   bool full = false;                // full variant (fan-in 30): direct float64 evaluation, gate_full.hip
   bool va = false;                  // CIFAR vAlexnet variant, gate_va.hip
+  bool fused = false;               // TT-small with stride-2 blocks only: one launch per block (gate_fused.hip), activations
+                                    // as compact rows; TTNET_GATE_UNFUSED=1 keeps the two-launch kernels of gate.hip
+  uint32_t *tap = nullptr;          // fused path: branch dwords of a non-last block, filled on demand by ttnet_read_stage
+  size_t tap_elems = 0;
   uint64_t *va_y = nullptr;         // vAlexnet: the concatenated block output [n][256][11] rows
   float *va_scale = nullptr, *va_shift = nullptr;   // vAlexnet stem BatchNorm folded
   float *last_float = nullptr;      // full variant: relu'd output of the last block before AvgPool2d
@@ -137,8 +144,8 @@ struct ttnet_plan {
     // own copies of those two kernels' launch parameters (argument values in 8-byte slots)
     hipKernelNodeParams first_p{}, last_p{};
     int first_nargs = 0;
-    uint64_t first_argv[8] = {}, last_argv[8] = {};
-    void *first_args[8] = {}, *last_args[8] = {};
+    uint64_t first_argv[12] = {}, last_argv[12] = {};
+    void *first_args[12] = {}, *last_args[12] = {};
     const void *x = nullptr;
     void *out = nullptr;
   };
@@ -151,6 +158,7 @@ struct ttnet_plan {
     std::vector<uint16_t *> x_cp;
     std::vector<std::array<uint16_t *, 4>> o;
     std::vector<uint64_t *> c3_tmp;
+    std::vector<uint32_t *> idx;
     uint64_t *va_y = nullptr;
     float *last_float = nullptr, *part = nullptr;
     uint16_t *feat = nullptr, *mid_frag = nullptr;
@@ -163,6 +171,11 @@ struct ttnet_plan {
   hipStream_t cap_stream = nullptr;
   bool graphs_ok = getenv("TTNET_NO_GRAPH") == nullptr;   // plain launches only when set (debugging)
   int64_t graph_replays = 0;
+  int64_t graph_captures = 0, graph_drops = 0;
+  std::string graph_off_reason;     // why graphs_ok went false (query "graphs_enabled" + ttnet_last_error)
+  // sticky range flag: one word of host-mapped memory that kernels set when a value leaves the
+  // range of the fp16 x 2 split (ttnet_common.h: split_out_of_range)
+  uint32_t *range_host = nullptr, *range_dev = nullptr;
   std::vector<Timing> timings;
   size_t timing_used = 0;
 
@@ -182,6 +195,12 @@ int ttnet::ensure_dynamic_lds(const void *kernel, size_t bytes) {
 }
 
 namespace {
+
+// Captured graphs bake in by-value kernel arguments derived from the weights (lin2's 1/prescale) and
+// the device addresses of tables: whenever a tensor, a table or the finalized state changes they are
+// all dropped (after a device synchronisation -- a replay may still be in flight) and re-captured
+// from the third forward on.
+int invalidate_graphs(ttnet_plan *pl);
 
 template <typename T>
 int dev_alloc(ttnet_plan *pl, T **out, size_t count, bool zero, size_t *account = nullptr) {
@@ -403,6 +422,11 @@ int build_geometry(ttnet_plan *pl) {
     h = ho; w = wo;
     in_planes = 2 * out_planes;
   }
+  if (d.variant == TTNET_SMALL && getenv("TTNET_GATE_UNFUSED") == nullptr) {
+    pl->fused = true;
+    for (const MultiHead &mh : pl->blocks)
+      pl->fused = pl->fused && fused_block_supported(mh.C, mh.H, mh.Ho, mh.stride, mh.c1.g.pad, mh.c1.g.kh, mh.c1.g.kw);
+  }
   const MultiHead &lb = pl->blocks.back();
   pl->featC = lb.cf.g.out_planes;
   pl->featPP = (lb.Ho / 2) * (lb.Wo / 2);
@@ -432,6 +456,16 @@ int alloc_workspace(ttnet_plan *pl) {
     pl->x_cp.assign(pl->blocks.size(), nullptr);
     for (size_t i = 0; i < pl->blocks.size(); ++i) {
       MultiHead &mh = pl->blocks[i];
+      if (pl->fused) {
+        // one activation layout: rows of uint64 / uint32 / uint16 words by width (the stem's output stays uint64)
+        const size_t bytes = (size_t)nb * mh.C * mh.H * (i == 0 ? 8 : row_bytes(mh.W));
+        TT_TRY(dev_alloc(pl, &pl->x_rp[i], (bytes + 7) / 8, true, ws));
+        TT_TRY(dev_alloc(pl, &pl->x_cp[i], 4, true, ws));
+        for (int b = 0; b < 4; ++b) TT_TRY(dev_alloc(pl, &mh.o[b], 8, true, ws));
+        mh.idx = nullptr;
+        if (mh.last) TT_TRY(dev_alloc(pl, &mh.idx, (size_t)nb * (mh.C / 8) * mh.Ho * mh.Wo, true, ws));
+        continue;
+      }
       TT_TRY(dev_alloc(pl, &pl->x_rp[i], (size_t)nb * mh.C * mh.H, true, ws));
       TT_TRY(dev_alloc(pl, &pl->x_cp[i], pl->full ? 8 : (size_t)nb * mh.H * mh.W * (mh.C / 16), true, ws));
       if (pl->full) TT_TRY(dev_alloc(pl, &mh.c3_tmp, (size_t)nb * mh.C * mh.H, true, ws));
@@ -460,9 +494,11 @@ void store_lane(ttnet_plan *pl, ttnet_plan::Lane &l) {
   l.x_cp = pl->x_cp;
   l.o.resize(pl->blocks.size());
   l.c3_tmp.resize(pl->blocks.size());
+  l.idx.resize(pl->blocks.size());
   for (size_t i = 0; i < pl->blocks.size(); ++i) {
     for (int b = 0; b < 4; ++b) l.o[i][b] = pl->blocks[i].o[b];
     l.c3_tmp[i] = pl->blocks[i].c3_tmp;
+    l.idx[i] = pl->blocks[i].idx;
   }
   l.va_y = pl->va_y;
   l.last_float = pl->last_float;
@@ -477,6 +513,7 @@ void load_lane(ttnet_plan *pl, const ttnet_plan::Lane &l) {
   for (size_t i = 0; i < pl->blocks.size(); ++i) {
     for (int b = 0; b < 4; ++b) pl->blocks[i].o[b] = l.o[i][b];
     pl->blocks[i].c3_tmp = l.c3_tmp[i];
+    pl->blocks[i].idx = l.idx[i];
   }
   pl->va_y = l.va_y;
   pl->last_float = l.last_float;
@@ -500,6 +537,9 @@ int upload_norm_table(ttnet_plan *pl) {
 
 int allocate(ttnet_plan *pl) {
   size_t *tb = &pl->table_bytes;
+  TT_HIP(hipHostMalloc((void **)&pl->range_host, sizeof(uint32_t), hipHostMallocMapped));
+  *pl->range_host = 0u;
+  TT_HIP(hipHostGetDevicePointer((void **)&pl->range_dev, pl->range_host, 0));
   const int kpad = (pl->inter + 15) / 16 * 16;
   for (auto &kv : pl->tensors) TT_TRY(dev_alloc(pl, (uint8_t **)&kv.second.dev, kv.second.bytes, true));
   if (pl->va) {
@@ -528,6 +568,11 @@ int allocate(ttnet_plan *pl) {
       TT_TRY(dev_alloc(pl, &b->near_dev, 1, true));
     }
   }
+  if (pl->fused)
+    for (auto &mh : pl->blocks) {
+      TT_TRY(dev_alloc(pl, (uint8_t **)&mh.img_dw, (size_t)mh.C * 16384, false, tb));
+      TT_TRY(dev_alloc(pl, (uint8_t **)&mh.img_c3, (size_t)(mh.C / 8) * 65536, false, tb));
+    }
   TT_TRY(dev_alloc(pl, &pl->w1f, frag_elems(pl->va ? 128 : (pl->inter + 127) / 128 * 128, pl->fcsize), false));
   TT_TRY(dev_alloc(pl, &pl->bn_scale, pl->inter, false));
   TT_TRY(dev_alloc(pl, &pl->bn_shift, pl->inter, false));
@@ -680,7 +725,7 @@ int run_full_block(ttnet_plan *pl, size_t i, int n, hipStream_t s) {
     if (mh.last) {
       a.out_rp = nullptr; a.out_float = pl->last_float;
       TT_TIMED(pl, "full.convf_last", s, launch_full_pw(a, s));
-      TT_TIMED(pl, "full.pool", s, launch_full_pool_split(pl->last_float, pl->feat, n, b.g.out_planes, mh.Ho, mh.Wo, s));
+      TT_TIMED(pl, "full.pool", s, launch_full_pool_split(pl->last_float, pl->feat, n, b.g.out_planes, mh.Ho, mh.Wo, pl->range_dev, s));
     } else {
       a.out_rp = pl->x_rp[i + 1]; a.out_float = nullptr;
       static const char *const kCf[4] = {"full.convf.f4", "full.convf.f5", "full.convf.f6", "full.convf.f7"};
@@ -706,7 +751,7 @@ int run_head(ttnet_plan *pl, int n, float *logits, int polynomial, const std::st
   const int s1 = gemm_f16x2_splits(n, pl->inter, pl->fcsize / 16);
   TT_TIMED(pl, "head.lin1", s, launch_gemm_f16x2(pl->feat, pl->w1f, pl->part, n, pl->inter, pl->fcsize, s1, s));
   TT_TIMED(pl, polynomial ? "head.bn_poly" : "head.bn", s,
-           launch_head_mid(pl->part, s1, pl->bn_scale, pl->bn_shift, pl->mid_frag, n, pl->inter, polynomial, s));
+           launch_head_mid(pl->part, s1, pl->bn_scale, pl->bn_shift, pl->mid_frag, n, pl->inter, polynomial, pl->range_dev, s));
   TT_TIMED(pl, "head.lin2", s,
            launch_lin2_f16x2(pl->mid_frag, pl->w2f, (const float *)pl->tensors[head + ".lin2.bias"].dev, pl->lin2_inv, logits, n,
                              pl->n_classes, pl->inter, s));
@@ -739,7 +784,19 @@ int run_from_blocks(ttnet_plan *pl, int n, float *logits, hipStream_t s) {
                  launch_xs_pf(n, mh.C, mh.Ho, mh.Wo, mh.cf.g.cout_g(), o64, mh.cf.table, pl->x_rp[i + 1], s));
       else
         TT_TIMED(pl, "gate_last", s,
-                 launch_xs_last(n, mh.C, mh.Ho, mh.Wo, mh.cf.g.cout_g(), o64, (const float *)mh.cf.table, pl->feat, s));
+                 launch_xs_last(n, mh.C, mh.Ho, mh.Wo, mh.cf.g.cout_g(), o64, (const float *)mh.cf.table, pl->feat, pl->range_dev, s));
+      continue;
+    }
+    if (pl->fused) {
+      static const char *kBlkNames[] = {"gate_block.f4", "gate_block.f5", "gate_block.f6", "gate_block.f7"};
+      FusedBlockArgs f{};
+      f.n = n; f.C = mh.C; f.H = mh.H; f.Ho = mh.Ho; f.off34 = mh.off34; f.last = mh.last ? 1 : 0;
+      f.x = pl->x_rp[i]; f.img_c3 = mh.img_c3; f.img_dw = mh.img_dw;
+      f.t_cf = mh.last ? nullptr : (const uint8_t *)mh.cf.table;
+      f.y = mh.last ? nullptr : (void *)pl->x_rp[i + 1];
+      f.idx = mh.last ? mh.idx : nullptr;
+      TT_TIMED(pl, kBlkNames[std::min<size_t>(i, 3)], s, launch_gate_block(f, s));
+      if (mh.last) TT_TIMED(pl, "gate_last", s, launch_gate_last(a, (const float *)mh.cf.table, pl->feat, pl->range_dev, s, mh.idx));
       continue;
     }
     TT_TIMED(pl, kS1Names[i], s, launch_gate_stage1(a, s));
@@ -747,11 +804,24 @@ int run_from_blocks(ttnet_plan *pl, int n, float *logits, hipStream_t s) {
       TT_TIMED(pl, kPfNames[i], s,
                launch_gate_pf(a, (const uint8_t *)mh.cf.table, pl->x_cp[i + 1], pl->x_rp[i + 1], s));
     } else {
-      TT_TIMED(pl, "gate_last", s, launch_gate_last(a, (const float *)mh.cf.table, pl->feat, s));
+      TT_TIMED(pl, "gate_last", s, launch_gate_last(a, (const float *)mh.cf.table, pl->feat, pl->range_dev, s));
     }
   }
   TT_TRY(run_head(pl, n, logits, 1, pl->head, s));
   pl->last_n = n;
+  return TTNET_OK;
+}
+
+// The range flag is raised by a kernel, i.e. asynchronously: the forward that overflowed has already
+// returned TTNET_OK.  Every later call on the plan fails until the flag is read (and cleared) with
+// ttnet_plan_query("range_overflow"); ttnet_read_stage checks it after its own synchronisation.
+int check_range(ttnet_plan *pl) {
+  if (pl->range_host && *(volatile uint32_t *)pl->range_host) {
+    set_error("an earlier forward on this plan met an activation outside the range of the fp16 x 2 operand split "
+              "(|input| or |feature| >= 4094, or NaN): its logits are invalid; ttnet_plan_query(\"range_overflow\") "
+              "reads and clears the flag");
+    return TTNET_E_RANGE;
+  }
   return TTNET_OK;
 }
 
@@ -768,7 +838,7 @@ int check_ready(ttnet_plan *pl, const void *in, int64_t n, const void *out) {
     set_error("batch %lld outside [1, max_batch=%d]", (long long)n, pl->desc.max_batch);
     return TTNET_E_INVALID;
   }
-  return TTNET_OK;
+  return check_range(pl);
 }
 
 BlockTT *find_block(ttnet_plan *pl, const char *name) {
@@ -844,6 +914,7 @@ int ttnet_plan_set_tensor(ttnet_plan *pl, const char *key, const void *ptr, cons
     return TTNET_E_INVALID;
   }
   TT_HIP(hipSetDevice(pl->device));
+  TT_TRY(invalidate_graphs(pl));
   TT_HIP(hipMemcpy(t.dev, ptr, t.bytes, on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
   t.set = true;
   pl->finalized = false;
@@ -860,6 +931,7 @@ int ttnet_plan_finalize(ttnet_plan *pl, void *stream) {
   }
   hipStream_t s = (hipStream_t)stream;
   TT_HIP(hipSetDevice(pl->device));
+  TT_TRY(invalidate_graphs(pl));
   for (auto &k : pl->key_order) {
     const Tensor &t = pl->tensors[k];
     if (t.required && !t.set) {
@@ -909,8 +981,10 @@ int ttnet_plan_finalize(ttnet_plan *pl, void *stream) {
     TT_HIP(hipMemcpy(pl->stem_wt, wf.data(), wf.size() * 2, hipMemcpyHostToDevice));
     TT_HIP(hipMemcpy(pl->stem_init, init, sizeof(init), hipMemcpyHostToDevice));
   }
-  for (auto &mh : pl->blocks)
+  for (auto &mh : pl->blocks) {
     for (BlockTT *b : {&mh.c1, &mh.c2, &mh.c3, &mh.cf}) TT_TRY(build_table(pl, *b, s));
+    if (pl->fused) TT_TRY(launch_fused_images(mh.c1.table, mh.c2.table, mh.c3.table, mh.C, mh.img_dw, mh.img_c3, s));
+  }
   {
     std::vector<double> sc, sh;
     TT_TRY(fold_bn(pl, pl->head + ".BN2", sc, sh));
@@ -956,8 +1030,8 @@ int forward_eager(ttnet_plan *pl, const void *x_dev, bool u8, int64_t n, float *
     return run_va_tail(pl, (int)n, logits_dev, s);
   }
   TT_TIMED(pl, "stem", s,
-           launch_stem(x_dev, u8, pl->norm_tab, pl->stem_wt, pl->stem_init, pl->x_rp[0], pl->full ? nullptr : pl->x_cp[0], (int)n,
-                       pl->p, s));
+           launch_stem(x_dev, u8, pl->norm_tab, pl->stem_wt, pl->stem_init, pl->x_rp[0], (pl->full || pl->fused) ? nullptr : pl->x_cp[0], (int)n,
+                       pl->p, pl->range_dev, s));
   return run_from_blocks(pl, (int)n, logits_dev, s);
 }
 
@@ -972,6 +1046,27 @@ void drop_graph(ttnet_plan::GraphEntry &e) {
   if (e.exec) (void)hipGraphExecDestroy(e.exec);
   if (e.graph) (void)hipGraphDestroy(e.graph);
   e = ttnet_plan::GraphEntry{};
+}
+
+int invalidate_graphs(ttnet_plan *pl) {
+  bool any = false;
+  for (auto &l : pl->lanes) any = any || !l.graphs.empty();
+  if (any) TT_HIP(hipDeviceSynchronize());
+  for (auto &l : pl->lanes) {
+    for (auto &kv : l.graphs) {
+      drop_graph(kv.second);
+      pl->graph_drops++;
+    }
+    l.graphs.clear();
+    l.eager_calls.clear();
+  }
+  return TTNET_OK;
+}
+
+void graphs_off(ttnet_plan *pl, const char *why) {
+  pl->graphs_ok = false;
+  pl->graph_off_reason = why;
+  (void)hipGetLastError();
 }
 
 // Copy a kernel node's launch parameters into storage we own.  sizes[i] = byte size of argument i.
@@ -1024,10 +1119,10 @@ bool capture_forward(ttnet_plan *pl, const void *x_dev, bool u8, int64_t n, floa
   if (hipGraphNodeGetType(e.first, &t0) != hipSuccess || hipGraphNodeGetType(e.last, &t1) != hipSuccess ||
       t0 != hipGraphNodeTypeKernel || t1 != hipGraphNodeTypeKernel || e.first == e.last)
     return false;
-  static const int first_sizes[8] = {8, 8, 8, 8, 8, 4, 4, 8};     // stem_pc_kernel(x, wfrag, init, rp, cp, p, n, norm_tab)
+  static const int first_sizes[9] = {8, 8, 8, 8, 8, 4, 4, 8, 8};  // stem_pc_kernel(x, wfrag, init, rp, cp, p, n, norm_tab, range_flag)
   static const int first_sizes_va[7] = {8, 8, 8, 8, 8, 8, 4};     // va_stem_kernel(x, w, bias, scale, shift, rp, n)
   static const int last_sizes[8] = {8, 8, 8, 4, 8, 4, 4, 4};      // lin2_f16x2_kernel(A, B, bias, inv, out, M, N, KS)
-  e.first_nargs = pl->va ? 7 : 8;
+  e.first_nargs = pl->va ? 7 : 9;
   if (!own_params(e.first, pl->va ? first_sizes_va : first_sizes, e.first_nargs, e.first_p, e.first_argv, e.first_args) ||
       !own_params(e.last, last_sizes, kLastKernelArgs, e.last_p, e.last_argv, e.last_args))
     return false;
@@ -1085,13 +1180,16 @@ int forward_impl(ttnet_plan *pl, int lane, const void *x_dev, bool u8, int64_t n
     ttnet_plan::GraphEntry e;
     if (!capture_forward(pl, x_dev, u8, n, logits_dev, e)) {
       drop_graph(e);
-      pl->graphs_ok = false;                                   // stay on plain launches
-      (void)hipGetLastError();
+      graphs_off(pl, "capture or instantiation of the forward failed");   // stay on plain launches
       return forward_eager(pl, x_dev, u8, n, logits_dev, s);
     }
+    pl->graph_captures++;
     if (L.graphs.size() >= 8) {                                // bound the cache: drop the smallest batch size
+      // its last replay may still be running on a stream this call knows nothing about
+      TT_HIP(hipDeviceSynchronize());
       drop_graph(L.graphs.begin()->second);
       L.graphs.erase(L.graphs.begin());
+      pl->graph_drops++;
     }
     it = L.graphs.emplace(key, e).first;
   }
@@ -1115,8 +1213,7 @@ int forward_impl(ttnet_plan *pl, int lane, const void *x_dev, bool u8, int64_t n
   if (!ok) {
     drop_graph(e);
     L.graphs.erase(it);
-    pl->graphs_ok = false;
-    (void)hipGetLastError();
+    graphs_off(pl, "hipGraphExecKernelNodeSetParams / hipGraphLaunch failed");
     return forward_eager(pl, x_dev, u8, n, logits_dev, s);
   }
   pl->last_n = n;
@@ -1163,7 +1260,7 @@ int ttnet_forward_from_stem_bits(ttnet_plan *pl, const uint64_t *rows_dev, int64
   const MultiHead &b0 = pl->blocks[0];
   TT_HIP(hipMemcpyAsync(pl->x_rp[0], rows_dev, (size_t)n * b0.C * b0.H * 8, hipMemcpyDeviceToDevice, s));
   if (pl->va) return run_va_tail(pl, (int)n, logits_dev, s);
-  if (!pl->full && !pl->xs) TT_TRY(launch_rp_to_cp(pl->x_rp[0], pl->x_cp[0], (int)n, b0.C, b0.H, b0.W, s));
+  if (!pl->full && !pl->xs && !pl->fused) TT_TRY(launch_rp_to_cp(pl->x_rp[0], pl->x_cp[0], (int)n, b0.C, b0.H, b0.W, s));
   return run_from_blocks(pl, (int)n, logits_dev, s);
 }
 
@@ -1187,7 +1284,7 @@ int ttnet_read_stage(ttnet_plan *pl, const char *stage, int64_t n, void *dst, si
     }
     TT_HIP(hipMemcpyAsync(dst, src, bytes, kind, s));
     TT_HIP(hipStreamSynchronize(s));
-    return TTNET_OK;
+    return check_range(pl);
   };
   if (pl->va) {
     if (st == "features.4") return copy_out(pl->x_rp[0], (size_t)n * 64 * 10 * 8);
@@ -1207,8 +1304,43 @@ int ttnet_read_stage(ttnet_plan *pl, const char *stage, int64_t n, void *dst, si
   for (size_t i = 0; i < pl->blocks.size(); ++i) {
     MultiHead &mh = pl->blocks[i];
     const std::string in_name = i == 0 ? std::string("features.3") : pl->blocks[i - 1].name;
+    if (st == in_name && pl->fused && i > 0) {          // compact rows -> the uint64 rows of the ABI
+      const size_t rows = (size_t)n * mh.C * mh.H;
+      uint64_t *tmp = nullptr;
+      TT_HIP(hipMalloc((void **)&tmp, rows * 8));
+      int r = launch_widen_rows(pl->x_rp[i], tmp, rows, mh.W, s);
+      if (r == TTNET_OK) r = copy_out(tmp, rows * 8);
+      (void)hipFree(tmp);
+      return r;
+    }
     if (st == in_name) return copy_out(pl->x_rp[i], (size_t)n * mh.C * mh.H * 8);
     for (int b = 0; b < 4; ++b) {
+      if (st == mh.name + ".out" + std::to_string(b + 1) && pl->fused) {
+        // the branch tensors never reach HBM on the fused path: a last block's dwords are its output; for
+        // the others the block is run once more on its (still resident) input with the tap buffer attached
+        const size_t words = (size_t)n * mh.C * mh.Ho, dwords = (size_t)pl->desc.max_batch * (mh.C / 8) * mh.Ho * mh.Wo;
+        const uint32_t *src = mh.idx;
+        if (!mh.last) {
+          if (pl->tap_elems < dwords) {
+            uint32_t *t = nullptr;
+            TT_TRY(dev_alloc(pl, &t, dwords, true));
+            pl->tap = t;
+            pl->tap_elems = dwords;
+          }
+          FusedBlockArgs f{};
+          f.n = (int)n; f.C = mh.C; f.H = mh.H; f.Ho = mh.Ho; f.off34 = mh.off34; f.last = 0;
+          f.x = pl->x_rp[i]; f.img_c3 = mh.img_c3; f.img_dw = mh.img_dw; f.t_cf = (const uint8_t *)mh.cf.table;
+          f.y = pl->x_rp[i + 1]; f.idx = pl->tap;
+          TT_TRY(launch_gate_block(f, s));
+          src = pl->tap;
+        }
+        uint64_t *tmp = nullptr;
+        TT_HIP(hipMalloc((void **)&tmp, words * 8));
+        int r = launch_branch_rows(src, tmp, (int)n, mh.C, mh.Ho, b, s);
+        if (r == TTNET_OK) r = copy_out(tmp, words * 8);
+        (void)hipFree(tmp);
+        return r;
+      }
       if (st == mh.name + ".out" + std::to_string(b + 1)) {
         const size_t words = (size_t)n * mh.C * mh.Ho;
         if (pl->xs || pl->full) return copy_out(mh.o[b], words * 8);
@@ -1323,9 +1455,16 @@ int ttnet_plan_set_table(ttnet_plan *pl, const char *name, const void *src_host,
       else ((uint16_t *)raw.data())[(size_t)grp * entries + idx] = (uint16_t)bits;
     }
   TT_HIP(hipSetDevice(pl->device));
+  TT_TRY(invalidate_graphs(pl));
   TT_HIP(hipMemcpy(b->table, raw.data(), raw.size(), hipMemcpyHostToDevice));
   b->user_table = true;
   b->near_ties = -1;
+  if (pl->fused)                            // the kernels read images derived from the conv1 / conv2 / conv3 tables
+    for (auto &mh : pl->blocks)
+      if (b == &mh.c1 || b == &mh.c2 || b == &mh.c3) {
+        TT_TRY(launch_fused_images(mh.c1.table, mh.c2.table, mh.c3.table, mh.C, mh.img_dw, mh.img_c3, nullptr));
+        TT_HIP(hipDeviceSynchronize());
+      }
   return TTNET_OK;
 }
 
@@ -1343,7 +1482,24 @@ int ttnet_plan_query(ttnet_plan *pl, const char *what, int64_t *out) {
   else if (w == "workspace_bytes") *out = (int64_t)pl->workspace_bytes;
   else if (w == "p") *out = pl->p;
   else if (w == "graph_replays") *out = pl->graph_replays;
-  else if (w == "graphs_enabled") *out = pl->graphs_ok ? 1 : 0;
+  else if (w == "graphs_enabled") {
+    *out = pl->graphs_ok ? 1 : 0;
+    if (!pl->graphs_ok)
+      set_error("graphs disabled: %s", pl->graph_off_reason.empty() ? "TTNET_NO_GRAPH is set" : pl->graph_off_reason.c_str());   // readable through ttnet_last_error
+  }
+  else if (w == "graph_captures") *out = pl->graph_captures;
+  else if (w == "graph_drops") *out = pl->graph_drops;
+  else if (w == "graphs_cached") {
+    int64_t c = 0;
+    for (auto &l : pl->lanes) c += (int64_t)l.graphs.size();
+    *out = c;
+  }
+  else if (w == "range_overflow") {          // read and clear (synchronises the device: the flag is raised by kernels)
+    TT_HIP(hipSetDevice(pl->device));
+    TT_HIP(hipDeviceSynchronize());
+    *out = *(volatile uint32_t *)pl->range_host ? 1 : 0;
+    *pl->range_host = 0u;
+  }
   else if (w == "lanes") *out = (int64_t)pl->lanes.size();
   else if (w.rfind("near_ties:", 0) == 0) {
     BlockTT *b = find_block(pl, w.c_str() + 10);
@@ -1401,6 +1557,7 @@ void ttnet_plan_destroy(ttnet_plan *pl) {
       if (kv.second.graph) (void)hipGraphDestroy(kv.second.graph);
     }
   if (pl->cap_stream) (void)hipStreamDestroy(pl->cap_stream);
+  if (pl->range_host) (void)hipHostFree(pl->range_host);
   for (void *ptr : pl->owned) (void)hipFree(ptr);
   delete pl;
 }

@@ -14,7 +14,8 @@
 // synthetic model the pre-activation error is <= 1e-6 (the reference's own float32
 // conv + BatchNorm deviates 4.9e-6 from float64), ten times below the near-tie band
 // (|pre| < 1e-5) inside which the output bits are allowed to differ; the bits are
-// oracle-checked, exact except at near ties.  Input range: |x| < 4094 (fp16 overflow of 16 x).
+// oracle-checked, exact except at near ties.  Input range: |x| < 4094 (fp16 overflow of 16 x); a
+// pooled value outside it raises the plan's range flag (ttnet.h: TTNET_E_RANGE), it never passes silently.
 // (Round-1 history: three bf16 terms / six products, 7e-8, cost twice the MFMAs and a third
 // LDS plane: 107 us at B = 256.)
 //
@@ -85,7 +86,7 @@ template <bool U8>
 __global__ __launch_bounds__(STEM_THREADS) void stem_pc_kernel(const void *__restrict__ xin, const uint4 *__restrict__ wfrag,
                                                                const float *__restrict__ init, uint64_t *__restrict__ rp,
                                                                uint16_t *__restrict__ cp, int p, int n_images,
-                                                               const uint32_t *__restrict__ norm_tab) {
+                                                               const uint32_t *__restrict__ norm_tab, uint32_t *range_flag) {
   const float *x = (const float *)xin;
   const uint8_t *xu8 = (const uint8_t *)xin;
   extern __shared__ __align__(16) uint8_t smem[];
@@ -145,6 +146,7 @@ __global__ __launch_bounds__(STEM_THREADS) void stem_pc_kernel(const void *__res
   // splits in turn needs 15.5 k cycles per item against 12 k for the consumers).
   constexpr int RPW = (3 * TR + PROD_WAVES - 1) / PROD_WAVES;        // rows per producer wave: 16
   float2 ra[RPW][2], rb[RPW][2];
+  bool out_of_range = false;             // a pooled, prescaled value beyond fp16 (|x| >= 4094): see split_out_of_range
   auto issue_loads = [&](int item) {
     const int n = item / (56 / SR), oy0 = (item % (56 / SR)) * SR;
     const int pw = wave - CONS_WAVES;                   // 0..3
@@ -227,6 +229,7 @@ __global__ __launch_bounds__(STEM_THREADS) void stem_pc_kernel(const void *__res
           if (lane + 64 * k < TW) {
             // pooled value exactly as the reference forms it (x 0.25), times the exact prescale
             const float v = (((ra[bi][k].x + ra[bi][k].y) + rb[bi][k].x) + rb[bi][k].y) * (colm[k] * rowm);
+            out_of_range |= split_out_of_range(v);
             const _Float16 h1 = (_Float16)v;
             const _Float16 h2 = (_Float16)(v - (float)h1);
             dst[64 * k] = __builtin_bit_cast(uint16_t, h1);
@@ -370,6 +373,7 @@ __global__ __launch_bounds__(STEM_THREADS) void stem_pc_kernel(const void *__res
       __syncthreads();
     }
     if (my_items > 0) emit_rows(first + (my_items - 1) * g, stage[(my_items - 1) & 1]);
+    if (out_of_range) *range_flag = 1u;
   } else {
     __syncthreads();
     __syncthreads();
@@ -444,7 +448,7 @@ void stem_norm_table(const float mean[3], const float stdv[3], uint32_t *tab) {
 }
 
 int launch_stem(const void *x, bool x_is_u8, const uint32_t *norm_tab, const void *wfrag, const float *init, uint64_t *rp,
-                uint16_t *cp, int n, int p, hipStream_t s) {
+                uint16_t *cp, int n, int p, uint32_t *range_flag, hipStream_t s) {
   if (p < 1 || p > 64 || (cp && p != 64)) {
     set_error("stem: p=%d outside [1,64] (channel words need p = 64)", p);
     return TTNET_E_UNSUPPORTED;
@@ -455,11 +459,11 @@ int launch_stem(const void *x, bool x_is_u8, const uint32_t *norm_tab, const voi
   if (x_is_u8) {
     TT_TRY(ensure_dynamic_lds((const void *)stem_pc_kernel<true>, lds));
     hipLaunchKernelGGL(stem_pc_kernel<true>, dim3(std::min(items, 256)), dim3(STEM_THREADS), lds, s, x, (const uint4 *)wfrag, init,
-                       rp, cp, p, n, norm_tab);
+                       rp, cp, p, n, norm_tab, range_flag);
   } else {
     TT_TRY(ensure_dynamic_lds((const void *)stem_pc_kernel<false>, lds));
     hipLaunchKernelGGL(stem_pc_kernel<false>, dim3(std::min(items, 256)), dim3(STEM_THREADS), lds, s, x, (const uint4 *)wfrag,
-                       init, rp, cp, p, n, norm_tab);
+                       init, rp, cp, p, n, norm_tab, range_flag);
   }
   TT_HIP(hipGetLastError());
   return TTNET_OK;

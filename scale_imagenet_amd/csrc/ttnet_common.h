@@ -108,7 +108,7 @@ __device__ inline uint32_t transpose16(uint32_t acc, const DwLaneConst &k) {
     constexpr int I = decltype(i)::value;
     const uint32_t partner = (uint32_t)__builtin_amdgcn_ds_swizzle((int)acc, 0x1F | (S[I] << 10));
     const uint32_t moved = __builtin_amdgcn_alignbit(partner, partner, k.rot[I]);
-    acc = (acc & k.keep[I]) | (moved & ~k.keep[I]);
+    acc = moved ^ ((moved ^ acc) & k.keep[I]);            // keep ? acc : moved, one v_bitop3_b32
   });
   return acc;
 }
@@ -151,10 +151,19 @@ __device__ inline void split_f16x2(float v, uint16_t &h1, uint16_t &h2) {
 }
 __device__ inline float f16_bits_to_float(uint16_t h) { return (float)__builtin_bit_cast(_Float16, h); }
 
+// Range of the split: the prescaled value must stay below the fp16 maximum (|activation| < 4094 at
+// ACT_PRESCALE 16).  The reference's float32 path has no such limit, so a value outside it must not
+// pass silently: kernels that split activations raise the plan's sticky flag (a word of host-mapped
+// memory, written only in the failing case), and the next C-ABI call on the plan returns
+// TTNET_E_RANGE (plan.hip).  NaN counts as out of range.
+__device__ inline bool split_out_of_range(float prescaled) { return !(__builtin_fabsf(prescaled) < 65504.0f); }
+
 // feature (image img, k-step ks of KS, element kk of 16) into lin1's A operand
-__device__ inline void store_feature(uint16_t *feat_frag, int img, int KS, int ks, int kk, float f) {
+__device__ inline void store_feature(uint16_t *feat_frag, int img, int KS, int ks, int kk, float f, uint32_t *range_flag) {
   uint16_t h1, h2;
-  split_f16x2(f * ACT_PRESCALE, h1, h2);
+  const float fs = f * ACT_PRESCALE;
+  if (split_out_of_range(fs)) *range_flag = 1u;
+  split_f16x2(fs, h1, h2);
   const int ln = (img & 31) + 32 * (kk >> 3), j = kk & 7;
   const size_t base = ((size_t)(img >> 5) * KS + ks) * SPLIT_PLANES;
   feat_frag[((base + 0) * 64 + ln) * 8 + j] = h1;
@@ -174,7 +183,7 @@ float weight_prescale(const float *w, size_t n);
 // init[64]: accumulator start values = the folded BN shift (both from stem_split_weights)
 // x: float32 NCHW, or (x_is_u8) uint8 NHWC with the normalisation table of stem_norm_table
 int launch_stem(const void *x, bool x_is_u8, const uint32_t *norm_tab, const void *wfrag, const float *init, uint64_t *rp,
-                uint16_t *cp, int n, int p, hipStream_t s);
+                uint16_t *cp, int n, int p, uint32_t *range_flag, hipStream_t s);
 void stem_norm_table(const float mean[3], const float stdv[3], uint32_t *tab /*[3][1024]*/);
 void stem_split_weights(const float *w /*[p][3][7][7]*/, const double *scale, const double *shift, int p, uint16_t *out,
                         float *init /*[64]*/);
@@ -201,13 +210,32 @@ int launch_gate_stage1(const GateBlockArgs &a, hipStream_t s);
 int launch_gate_pf(const GateBlockArgs &a, const uint8_t *t_cf, uint16_t *out_cp, uint64_t *out_rp, hipStream_t s);
 // convf of the last block through the float table, AvgPool2d(2) fused; the features are
 // written pre-split for lin1: fragment-ordered fp16 planes [n/32][(g*PP+pp)][2][64][8]
-int launch_gate_last(const GateBlockArgs &a, const float *t_last, void *feat_frag, hipStream_t s);
+// (idx != nullptr: the branch dwords of gate_fused.hip instead of the four word tensors o1..o4)
+int launch_gate_last(const GateBlockArgs &a, const float *t_last, void *feat_frag, uint32_t *range_flag, hipStream_t s,
+                     const uint32_t *idx = nullptr);
+// gate_fused.hip: one launch per stride-2 block of TT-small, branch tensors kept on chip.
+// Activations: one layout, rows [n][C][H] of uint64 (W > 32) / uint32 (W > 16) / uint16 words.
+struct FusedBlockArgs {
+  int n, C, H, Ho, off34, last;
+  const void *x;             // block input rows
+  const void *img_c3, *img_dw;   // table images built by launch_fused_images
+  const uint8_t *t_cf;       // binarised Block_convf table [C/4][65536] (not read by a last block)
+  void *y;                   // output rows [n][2C][Ho] (binarised blocks)
+  uint32_t *idx;             // branch dwords [n][C/8][Ho*Ho]: output of a last block (read by gate_last), optional tap otherwise
+};
+bool fused_block_supported(int C, int H, int Ho, int stride, int pad, int kh, int kw);
+int row_bytes(int W);
+int launch_gate_block(const FusedBlockArgs &f, hipStream_t s);
+int launch_fused_images(const void *t_dw1, const void *t_dw2, const void *t_c3, int C, void *img_dw, void *img_c3, hipStream_t s);
+int launch_branch_rows(const uint32_t *idx, uint64_t *rows, int n, int C, int Ho, int branch, hipStream_t s);
+int launch_widen_rows(const void *src, uint64_t *dst, size_t count, int W, hipStream_t s);
+int launch_narrow_rows(const uint64_t *src, void *dst, size_t count, int W, hipStream_t s);
 // x-small variant (fan-in 4, gate_xs.hip): everything on row-packed planes
 int launch_xs_branches(const GateBlockArgs &a, const void *t_c3, uint64_t *const o[4], hipStream_t s);
 int launch_xs_pf(int n, int C, int Ho, int Wo, int cout_g, uint64_t *const o[4], const void *t_cf, uint64_t *out_rp,
                  hipStream_t s);
 int launch_xs_last(int n, int C, int Ho, int Wo, int cout_g, uint64_t *const o[4], const float *t_last, void *feat_frag,
-                   hipStream_t s);
+                   uint32_t *range_flag, hipStream_t s);
 // full variant (fan-in 30, gate_full.hip): direct float64 evaluation on row-packed planes
 struct FullDwArgs {
   int n, C, H, W;           // input planes
@@ -235,7 +263,7 @@ int launch_full_dw(const FullDwArgs &a, hipStream_t s);
 int launch_full_pw(const FullPwArgs &a, hipStream_t s);
 int launch_rp_majority(const uint64_t *x, uint64_t *out, int n, int C, int H, int W, int Ho, int pad_t, int pad_l,
                        hipStream_t s);
-int launch_full_pool_split(const float *x, void *feat_frag, int n, int C, int H, int W, hipStream_t s);
+int launch_full_pool_split(const float *x, void *feat_frag, int n, int C, int H, int W, uint32_t *range_flag, hipStream_t s);
 // CIFAR vAlexnet variant (gate_va.hip)
 int launch_va_stem(const float *x, const float *w, const float *bias, const float *scale, const float *shift,
                    uint64_t *rp, int n, hipStream_t s);
@@ -258,7 +286,7 @@ int launch_split_to_frag(const float *src, void *dst, int R, int K, int rows_pad
 // z = sum_s part; z = z*scale+shift; y = 0.47+0.5z+0.09z^2 (Classifier_scale middle), written as lin2's
 // split A operand: fragment order, rows = images (allocate padded to 64), ceil(N/16) k-steps
 int launch_head_mid(const float *part, int splits, const float *scale, const float *shift, void *mid_frag, int M, int N,
-                    int polynomial, hipStream_t s);
+                    int polynomial, uint32_t *range_flag, hipStream_t s);
 // logits[M][N] = mid[M][K] * W2[N][K]^T * inv + bias on split operands (w2f rows padded to 64)
 int launch_lin2_f16x2(const void *mid_frag, const void *w2f, const float *bias, float inv, float *out, int M, int N, int K,
                       hipStream_t s);

@@ -80,18 +80,51 @@ dist.destroy_process_group()
 '''
 
 
-@pytest.mark.parametrize("n_total", [4, 5])
-def test_two_rank_gloo_shard_and_gather(tmp_path, n_total):
+@pytest.mark.parametrize("n_total,launcher", [(4, "env"), (5, "spawn_ranks")])
+def test_two_rank_gloo_shard_and_gather(tmp_path, n_total, launcher):
+    """World size 2 over gloo: once with the rank environment written by hand (what torch.distributed.run
+    provides), once through the package's own launcher (what `python bench.py --gpus 2` uses)."""
     out = str(tmp_path / "all.npy")
     script = tmp_path / "worker.py"
     script.write_text(_WORKER.format(root=ROOT, n_total=n_total, out=out))
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29600 + n_total), WORLD_SIZE="2")
-    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)))
-             for r in range(2)]
-    for p in procs:
-        assert p.wait(timeout=300) == 0
+    if launcher == "env":
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29600 + n_total), WORLD_SIZE="2")
+        procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)))
+                 for r in range(2)]
+        for p in procs:
+            assert p.wait(timeout=300) == 0
+    else:
+        from scale_imagenet_amd.launch import spawn_ranks
+        assert spawn_ranks([str(script)], 2, timeout_s=300) == 0
     got = np.load(out)
     ref = golden_npz("xsmall")["logits"][:n_total]
     assert got.shape == ref.shape
     assert np.abs(got - ref).max() <= 1e-5          # same images, same order, whatever the split
     assert np.array_equal(got.argmax(1), ref.argmax(1))
+
+
+def test_launcher_reports_a_failing_rank(tmp_path):
+    from scale_imagenet_amd.launch import spawn_ranks, under_launcher
+    assert not under_launcher()
+    script = tmp_path / "w.py"
+    script.write_text("import os, sys, time\n"
+                      "assert os.environ['WORLD_SIZE'] == '3' and os.environ['MASTER_ADDR'] == '127.0.0.1'\n"
+                      "if os.environ['RANK'] == '1': sys.exit(7)\n"
+                      "time.sleep(30)\n")
+    t0 = __import__("time").monotonic()
+    assert spawn_ranks([str(script)], 3, timeout_s=60) == 7          # first failure wins; the others are stopped
+    assert __import__("time").monotonic() - t0 < 20
+    ok = tmp_path / "ok.py"
+    ok.write_text("import os\nprint('rank', os.environ['RANK'])\n")
+    assert spawn_ranks([str(ok)], 2, timeout_s=60) == 0
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU failure mode of the self-launching bench")
+def test_bench_self_launch_fails_loudly_without_a_gpu():
+    """`python bench.py --gpus 2` without a rank environment starts its own ranks (and must not touch the
+    GPU itself to do so); here they find no device, so the parent has to exit non-zero."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+                        "--batch", "2"], capture_output=True, text=True, timeout=600,
+                       env=dict(os.environ, TTNET_DIST_BACKEND="gloo"))
+    assert r.returncode != 0
+    assert "HIP device" in r.stderr

@@ -12,14 +12,28 @@ import numpy as np
 import pytest
 import torch
 
-from _util import args_for, golden_json, golden_npz, sha, spec_and_state
+import json
+
+from _util import GOLD, args_for, golden_json, golden_npz, sha, spec_and_state
 from oracle import ttnet_bits as OB
 from oracle import ttnet_float as OF
 from scale_imagenet_amd import _lib, synth, ttnet
 
 pytestmark = pytest.mark.gpu
 
-LOGIT_TOL = 1e-5
+LOGIT_TOL = 1e-5          # the north star's bound; the only absolute logit tolerance in this file
+# The reference's own float32 head is not exact: tests/golden/ref_spread.json (written by
+# oracle/gen_golden.py from the imported reference) records, per variant, how far its committed
+# logits sit from the float64 evaluation of the same head on its own features (ref_vs_exact:
+# 5.8e-6 / 1.0e-5 / 6.8e-6) and how far they move with its thread count alone (4.4e-6 / 6.3e-6 /
+# 1.9e-6) at logits of magnitude ~3.  So: |hip - exact| <= 1e-5, and against the reference capture
+# the allowance is 1e-5 + that committed distance.
+with open(os.path.join(GOLD, "ref_spread.json")) as _f:
+    REF_SPREAD = json.load(_f)["variants"]
+
+
+def ref_allowance(variant):
+    return LOGIT_TOL + REF_SPREAD[variant]["ref_vs_exact"]
 
 
 @pytest.fixture(scope="module")
@@ -61,8 +75,25 @@ def small_model(dev):
     return _model("small", dev)
 
 
+def scaled_tol(ref):
+    """1e-5 is stated for logits of the reference's scale (|logit| <= ~3 on the golden images).  Inputs
+    far from the calibration set (random stem bits, uncalibrated heads) give logits k times larger,
+    where float32 itself no longer resolves 1e-5 (an ulp at 64 is 7.6e-6): the bound scales with k."""
+    return LOGIT_TOL * max(1.0, float(np.abs(ref).max()) / 4.0)
+
+
+@pytest.fixture(scope="module")
+def oracle_small_rows():
+    """features.5 of the 8 golden images as the reference computes it (row-packed)."""
+    return OB.pack_rows(_oracle_taps("small")[1]["features.5"].astype(np.uint8))
+
+
 @pytest.fixture(scope="module")
 def oracle_taps(variant):
+    return _oracle_taps(variant)
+
+
+def _oracle_taps(variant):
     """Reference-identical stages for the 8 golden images (the float oracle is pinned to the
     reference bit for bit by tests/test_oracle_golden.py)."""
     if variant not in _TAPS:
@@ -103,15 +134,19 @@ def test_truth_tables_match_float64_oracle(model, variant):
     for b in spec.block_tts():
         info = j["luts"][b.name]
         tab = model.get_table(b.name)
-        if b.last:
-            ref, _ = OB.build_lut(st, b, groups=[0, 37])
-            assert np.abs(tab[[0, 37]] - ref).max() <= 1e-6
+        if b.last:           # the float table of the last block: every group, in chunks (float64 -> float32 once)
+            worst = 0.0
+            for g0 in range(0, b.groups, 8):
+                gl = list(range(g0, min(b.groups, g0 + 8)))
+                ref, _ = OB.build_lut(st, b, groups=gl)
+                worst = max(worst, float(np.abs(tab[gl] - ref).max()))
+            assert worst <= 1e-6, (b.name, worst)
             continue
         got = sha(np.packbits(tab, axis=1, bitorder="little"))
         if got != info["f64_sha256"]:                  # an erf ulp could move an exact tie: then
             ref, near = OB.build_lut(st, b)            # every difference must be a near tie
             d = np.argwhere(ref != tab)
-            assert len(d) and near[tuple(d.T)].all(), f"{b.name}: table differs outside the near-tie set"
+            assert len(d) > 0 and near[tuple(d.T)].all(), f"{b.name}: table differs outside the near-tie set"
         assert ties[b.name] == info["near_ties"], b.name
         flips = np.array(info["ref_differs_from_f64_at"], dtype=np.int64).reshape(-1, 3)
         patched = tab.copy()
@@ -135,7 +170,12 @@ def test_stem_bits(model, variant, dev, oracle_taps):
     for d in diff:
         assert abs(pre[tuple(d)]) < OB.NEAR_TIE, f"stem bit {tuple(d)} differs away from a tie: pre={pre[tuple(d)]}"
     print(f"stem: {len(diff)} of {bits.size} bits differ from the reference (all near ties)")
-    assert np.array_equal(rows[:2], g["rows:features.3"]) or len(diff) > 0
+    if len(diff) == 0:       # then the packed words are the committed ones, bit for bit
+        assert np.array_equal(rows[:2], g["rows:features.3"])
+    else:                    # only images that own one of the listed differences may differ
+        dirty = set(int(d[0]) for d in diff)
+        for i in (0, 1):
+            assert i in dirty or np.array_equal(rows[i], g["rows:features.3"][i])
 
 
 def test_stem_bits_batch64_vs_float64(small_model, dev):
@@ -201,10 +241,12 @@ def test_gate_path_bit_exact_and_logits(model, variant, dev, oracle_taps):
         spec, st = spec_and_state(variant)
         exact = OB.head64(oracle_taps[1]["flatten"], st, f"features.{4 + len(spec.blocks) + 2}")
         ref_dev = float(np.abs(g["logits"] - exact).max())
-        print(f"{variant}: |gpu-exact| {np.abs(logits - exact).max():.2e}  |ref-exact| {ref_dev:.2e}  "
-              f"|gpu-ref| {np.abs(logits - g['logits']).max():.2e}")
+        print(f"{variant}: |gpu-exact| {np.abs(logits - exact).max():.2e}  |ref-exact| {ref_dev:.2e} "
+              f"(fixture {REF_SPREAD[variant]['ref_vs_exact']:.2e})  |gpu-ref| {np.abs(logits - g['logits']).max():.2e}")
+        # (ref_dev is recomputed from THIS box's oracle features, whose float32 convolutions differ in the
+        # last bits from the build container's: 6.0e-6 vs 5.8e-6 for TT-small; the allowance is the fixture's)
         assert np.abs(logits - exact).max() <= LOGIT_TOL
-        assert np.abs(logits - g["logits"]).max() <= LOGIT_TOL + ref_dev
+        assert np.abs(logits - g["logits"]).max() <= ref_allowance(variant)
         assert np.array_equal(logits.argmax(1), g["argmax"])
     finally:
         for name, tab in saved.items():
@@ -229,15 +271,18 @@ def test_end_to_end_forward(model, variant, dev, oracle_taps):
     assert clean.sum() >= n - 2
     exact = OB.head64(oracle_taps[1]["flatten"], spec_and_state(variant)[1], f"features.{4 + len(spec.blocks) + 2}")
     assert np.abs(y[clean] - exact[clean]).max() <= LOGIT_TOL
-    assert np.abs(y[clean] - g["logits"][clean]).max() <= LOGIT_TOL + float(np.abs(g["logits"] - exact).max())
+    assert np.abs(y[clean] - g["logits"][clean]).max() <= ref_allowance(variant)
     assert np.array_equal(y[clean].argmax(1), g["argmax"][clean])
-    assert np.abs(y - g["logits"]).max() < 1e-2          # a near-tie flip moves logits a little, never far
+    # an image that crossed a listed near tie (at most 2 of them, asserted above) carries a few flipped
+    # bits through the blocks: its logits are NOT covered by the 1e-5 claim; they stay close (sanity)
+    if (~clean).any():
+        assert np.abs(y[~clean] - g["logits"][~clean]).max() < 1e-2
 
 
-def test_full_batch_properties(small_model, dev):
-    model = small_model
+def test_full_batch_properties(small_model, dev, oracle_small_rows):
     """BASELINE size (batch 256): determinism, batch-composition invariance of the integer
     path, and agreement of a 256-image forward with 8-image forwards."""
+    model = small_model
     n = 256
     x = torch.from_numpy(synth.synth_images(n)).to(dev)
     with torch.no_grad():
@@ -256,7 +301,10 @@ def test_full_batch_properties(small_model, dev):
     assert np.array_equal(fa, f1[8:16])
     assert (ya - y1[8:16]).abs().max().item() <= LOGIT_TOL
     g = golden_npz("small")
-    assert np.array_equal(y1[:8].argmax(1).cpu().numpy(), g["argmax"]) or True
+    # the 8 golden images lead the batch: those whose gate bits equal the reference's are top-1 equal
+    same = (s5[:8] == oracle_small_rows).reshape(8, -1).all(axis=1)
+    assert same.sum() >= 6
+    assert np.array_equal(y1[:8].argmax(1).cpu().numpy()[same], g["argmax"][same])
     assert s5.shape == (n, 256, 15)
     assert len(set(y1.argmax(1).tolist())) > 20          # the synthetic classifier is not degenerate
 
@@ -279,8 +327,8 @@ def test_graph_replay_matches_plain_launches(small_model, dev):
         got = [model(x).clone() for x in xs]        # replays with patched pointers
         rows = model.read_stage("features.3", n).copy()
     torch.cuda.synchronize()
-    if plan.query("graphs_enabled"):
-        assert plan.query("graph_replays") > before
+    assert plan.query("graphs_enabled") == 1, _lib.load().ttnet_last_error()     # gfx950: capture must work
+    assert plan.query("graph_replays") > before
     for g, w in zip(got, want):
         assert torch.equal(g, w)
     assert rows.shape[0] == n
@@ -423,7 +471,8 @@ def test_majority_and_padding_edges(model, variant, dev):
         for stage in ("features.4.out1", "features.4.out3", "features.4.out4", "features.4", "features.5",
                       "features.6.out2", "features.6.out3"):
             assert np.array_equal(model.read_stage(stage, 2), OB.pack_rows(bt[stage])), (fill, stage)
-        assert np.abs(y - ref).max() <= 2e-5
+        print(f"{variant} fill={fill}: |logit| max {np.abs(ref).max():.2f}, |gpu - exact| {np.abs(y - ref).max():.2e}")
+        assert np.abs(y - ref).max() <= scaled_tol(ref)  # ref: the float64 head on the bit oracle's features
 
 
 def test_random_bits_against_bit_oracle(model, variant, dev):
@@ -445,7 +494,8 @@ def test_random_bits_against_bit_oracle(model, variant, dev):
             assert np.abs(model.read_stage("flatten", 3) - bt[stage]).max() <= 5e-7 * max(1.0, np.abs(bt[stage]).max()) + 1e-6
         else:
             assert np.array_equal(model.read_stage(stage, 3), OB.pack_rows(bt[stage])), stage
-    assert np.abs(y - ref).max() <= 2e-5
+    print(f"{variant} random bits: |logit| max {np.abs(ref).max():.2f}, |gpu - exact| {np.abs(y - ref).max():.2e}")
+    assert np.abs(y - ref).max() <= scaled_tol(ref)
 
 
 def test_errors_are_loud(small_model, dev):
@@ -513,9 +563,13 @@ def test_cabi_comm_single_rank(dev):
 @pytest.mark.parametrize("layers", [0, 2, 3, 4])
 def test_other_depths_against_the_oracle(dev, layers):
     """--layers 0 / 2 (two and four stride-2 blocks) and 3 / 4 (a stride-1 first block, and a second
-    one at 29x29; TT_general_imagenet_v2_small.py:172-181): the HIP path is checked against the
-    oracle (pinned to the reference for every depth) on the same synthetic weights: gate bits from the oracle's stem bits must be
-    identical (tables are float64 on both sides), logits within 1e-5 of the exact head."""
+    one at 29x29; TT_general_imagenet_v2_small.py:172-181).  Three independent checks:
+      1. every GPU-built truth table equals the float64 oracle table (OB.build_lut) -- for the float
+         table of the last block: 8 of its 64 / 128 groups (first, last and six in between);
+      2. the gate path on the GPU's stem bits is bit-identical to the bit oracle RUN ON THE ORACLE'S
+         OWN TABLES at every stage, and the logits are within the tolerance of the exact head;
+      3. for --layers 3 / 4 the stages of the images in tests/golden/ref_small_l<k>.npz (the imported
+         reference's own per-stage hashes) are reproduced wherever the stem bits are, and top-1 agrees."""
     from argparse import Namespace
     from scale_imagenet_amd.spec import make_spec
     spec = make_spec("small", 8, 8, layers)
@@ -528,7 +582,24 @@ def test_other_depths_against_the_oracle(dev, layers):
         y = m(torch.from_numpy(x).to(dev)).cpu().numpy()
     stem_rows = m.read_stage("features.3", 3)
     bits = OB.unpack_rows(stem_rows, 56)
-    luts = {b.name: m.get_table(b.name) for b in spec.block_tts()}
+    # 1. tables: GPU float64 == numpy float64 (differences only where the oracle itself sees a near tie)
+    luts = {}
+    for b in spec.block_tts():
+        tab = m.get_table(b.name)
+        if b.last:
+            gl = sorted(set([0, b.groups - 1] + list(range(5, b.groups, max(1, b.groups // 6)))))[:8]
+            ref, _ = OB.build_lut(st, b, groups=gl)
+            assert np.abs(tab[gl] - ref).max() <= 1e-6, b.name
+            luts[b.name] = tab                      # (the remaining groups are exercised through check 2's logits)
+            continue
+        ref, near = OB.build_lut(st, b)
+        d = np.argwhere(ref != tab)
+        assert near[tuple(d.T)].all(), f"--layers {layers} {b.name}: table differs outside the near-tie set"
+        luts[b.name] = ref
+        if len(d):                                  # run the bit oracle on exactly what the GPU looks up
+            luts[b.name] = tab
+            print(f"--layers {layers} {b.name}: {len(d)} near-tie entries differ from numpy float64")
+    # 2. integer path vs the bit oracle on the oracle's tables
     bt = {}
     ref = OB.forward_from_stem_bits(bits, st, spec, luts, bt)
     for stage, want in bt.items():
@@ -536,16 +607,157 @@ def test_other_depths_against_the_oracle(dev, layers):
             continue
         assert np.array_equal(m.read_stage(stage, 3), OB.pack_rows(want)), (layers, stage)
     assert y.shape == (3, 1000)
-    scale = max(1.0, float(np.abs(ref).max()))
-    assert np.abs(y - ref).max() <= 1e-5 * scale, (layers, np.abs(y - ref).max(), scale)
-    if layers >= 3:      # the reference's own logits for these depths (oracle/gen_golden.py depth)
-        from _util import GOLD
+    print(f"--layers {layers}: |logit| max {np.abs(ref).max():.1f} (uncalibrated head), |gpu - exact| {np.abs(y - ref).max():.2e}")
+    assert np.abs(y - ref).max() <= scaled_tol(ref), (layers, np.abs(y - ref).max())
+    # 3. the reference's own capture (oracle/gen_golden.py depth)
+    if layers >= 3:
         with np.load(os.path.join(GOLD, f"ref_small_l{layers}.npz")) as z:
-            want = z["logits"]
+            want, names, shas = z["logits"], [str(v) for v in z["stage_names"]], [str(v) for v in z["stage_sha"]]
         k = want.shape[0]
+        same_stem = sha(stem_rows[:k]) == shas[names.index("features.3")]
+        compared = 0
+        if same_stem:
+            for nm, hs in zip(names, shas):
+                if nm == "features.3":
+                    continue
+                if sha(m.read_stage(nm, 3)[:k]) == hs:
+                    compared += 1
+                else:                               # only a listed float32-vs-float64 near tie may do this
+                    print(f"--layers {layers}: stage {nm} differs from the reference capture (table near tie)")
+            print(f"--layers {layers}: {compared} of {len(names) - 1} block outputs hash-identical to the reference capture")
         assert np.array_equal(y[:k].argmax(1), want.argmax(1))
-        assert np.abs(y[:k] - want).max() < 1e-2 * scale       # a near-tie flip moves logits a little, never far
+        if same_stem and compared == len(names) - 1:
+            assert np.abs(y[:k] - want).max() <= scaled_tol(want) + REF_SPREAD["small"]["ref_vs_exact"] * max(1.0, float(np.abs(want).max()) / 4.0)
         print(f"--layers {layers}: |gpu - reference| {np.abs(y[:k] - want).max():.2e} on {k} images")
+
+
+def test_reload_after_capture_uses_the_new_weights(dev):
+    """A captured hipGraph bakes in by-value arguments derived from the weights (lin2's 1/prescale):
+    three forwards (-> capture), then load_state_dict with lin2.weight x 4 (its prescale crosses two
+    powers of two) and a changed BatchNorm: the next forward must equal a fresh model's, and the plan
+    must have dropped its graphs and go on to capture and replay new ones."""
+    spec, st = spec_and_state("small")
+    m = ttnet.TT_vf_19lv3_imgnet_small(args_for("small"))
+    m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in st.items()})
+    m = m.to(dev).eval().reserve(8)
+    x = torch.from_numpy(synth.synth_images(8)).to(dev)
+    with torch.no_grad():
+        for _ in range(4):
+            y_old = m(x).clone()
+    plan = m._any_plan()
+    assert plan.query("graphs_enabled") == 1 and plan.query("graph_replays") >= 1 and plan.query("graphs_cached") == 1
+    st2 = {k: v.copy() for k, v in st.items()}
+    st2["features.9.lin2.weight"] *= 4.0
+    st2["features.9.BN2.weight"] = (st2["features.9.BN2.weight"] * 0.5).astype(np.float32)
+    m.load_state_dict({"module." + k: torch.from_numpy(v) for k, v in st2.items()})     # a DataParallel checkpoint
+    with torch.no_grad():
+        y_new = m(x).clone()
+    assert plan.query("graphs_cached") == 0 and plan.query("graph_drops") >= 1
+    fresh = ttnet.TT_vf_19lv3_imgnet_small(args_for("small"))
+    fresh.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in st2.items()})
+    fresh = fresh.to(dev).eval().reserve(8)
+    with torch.no_grad():
+        want = fresh(x).clone()
+        replays = plan.query("graph_replays")
+        for _ in range(4):
+            y_again = m(x).clone()
+    assert torch.equal(y_new, want) and torch.equal(y_again, want)
+    assert not torch.equal(y_new, y_old)
+    assert plan.query("graph_replays") > replays and plan.query("graphs_cached") == 1
+
+
+def test_graph_cache_eviction_and_pointer_patching(dev):
+    """Round 1 saw one abort in this area ('The graph-replay abort'): the kernel-parameter
+    arrays handed to hipGraphExecKernelNodeSetParams must be storage the plan owns, also after the
+    GraphEntry has been moved into the cache map.  Ten batch sizes overflow the 8-entry cache (entries
+    are evicted only after a device synchronisation), every replay gets fresh input / output buffers,
+    and every result must equal the plain launches."""
+    spec, st = spec_and_state("small")
+    m = ttnet.TT_vf_19lv3_imgnet_small(args_for("small"))
+    m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in st.items()})
+    m = m.to(dev).eval().reserve(16)
+    xs = torch.from_numpy(synth.synth_images(16)).to(dev)
+    m.set_profiling(True)                           # plain launches
+    with torch.no_grad():
+        want = m(xs).clone()
+    m.set_profiling(False)
+    plan = m._any_plan()
+    sizes = [3, 4, 5, 6, 7, 9, 10, 11, 12, 13]
+    with torch.no_grad():
+        for n in sizes:
+            for rep in range(4):                    # two plain calls, the capture, one replay with new buffers
+                y = m(xs[:n].clone())
+            assert torch.equal(y, want[:n]), n
+        for n in sizes:                             # evicted sizes are captured again, cached ones replayed
+            for rep in range(3):
+                y = m(xs[:n].clone())
+            assert torch.equal(y, want[:n]), n
+    torch.cuda.synchronize()
+    assert plan.query("graphs_enabled") == 1, _lib.load().ttnet_last_error()
+    assert plan.query("graph_drops") >= 2 and plan.query("graphs_cached") <= 8
+    assert plan.query("graph_captures") >= len(sizes)
+
+
+def test_dataparallel_wrapper_as_main_py_builds_it(dev):
+    """main.py:192 wraps the model in nn.DataParallel and :222 loads a `module.`-prefixed checkpoint
+    INTO THE WRAPPER; :251 / :261 then call wrapper.eval() and wrapper(inputs).  With one visible
+    device DataParallel calls the module directly (no replicate)."""
+    spec, st = spec_and_state("small")
+    g = golden_npz("small")
+    net = torch.nn.DataParallel(ttnet.TT_vf_19lv3_imgnet_small(args_for("small")), device_ids=[0]).cuda()
+    ckpt = {"model_state_dict": {"module." + k: torch.from_numpy(v.copy()) for k, v in st.items()}}
+    assert list(net.state_dict().keys()) == list(ckpt["model_state_dict"].keys())
+    net.load_state_dict(ckpt["model_state_dict"])           # strict, as main.py:222
+    net.eval()
+    n = int(g["n_images"])
+    x = torch.from_numpy(synth.synth_images(n))
+    with torch.no_grad():
+        y = net(x.cuda(non_blocking=True))
+        plain = _model("small", dev)(x.to(dev))
+    assert y.device.type == "cuda" and y.shape == (n, 1000)
+    assert torch.equal(y, plain)
+    assert (y.argmax(1).cpu().numpy() == g["argmax"]).sum() >= n - 2     # (near-tie images: test_end_to_end_forward)
+
+
+def test_values_outside_the_split_range_are_loud(dev):
+    """The float stages carry f32 operands as two fp16 terms after a x16 prescale: |v| < 4094
+    (ttnet.h).  The reference has no such limit, so an input beyond it must not pass silently: the
+    kernel raises the plan's sticky flag and the next call fails with TTNET_E_RANGE until the flag
+    has been read."""
+    spec, st = spec_and_state("small")
+    m = ttnet.TT_vf_19lv3_imgnet_small(args_for("small"))
+    m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in st.items()})
+    m = m.to(dev).eval().reserve(4)
+    x = torch.from_numpy(synth.synth_images(2)).to(dev)
+    with torch.no_grad():
+        y0 = m(x).clone()
+        plan = m._any_plan()
+        assert plan.query("range_overflow") == 0
+        bad = x.clone()
+        bad[1, 2, 100:104, 50:54] = 30000.0          # pooled value 30000 -> 480000 after the prescale
+        m(bad)                                       # asynchronous: returns before the kernel has run
+        torch.cuda.synchronize()
+        with pytest.raises(_lib.TTNetError) as ei:
+            m(x)
+        assert ei.value.status == -6 and b"range" in _lib.load().ttnet_last_error()
+        assert plan.query("range_overflow") == 1     # read and clear
+        assert plan.query("range_overflow") == 0
+        assert torch.equal(m(x), y0)
+        nan = x.clone()
+        nan[0, 0, 0, 0] = float("nan")
+        m(nan)
+        torch.cuda.synchronize()
+        with pytest.raises(_lib.TTNetError):
+            m.read_stage("features.3", 2)
+        assert plan.query("range_overflow") == 1
+    # a classifier whose BatchNorm1d blows the polynomial's input up leaves the range inside the head
+    st2 = {k: v.copy() for k, v in st.items()}
+    st2["features.9.BN2.weight"] = (st2["features.9.BN2.weight"] * 1e4).astype(np.float32)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in st2.items()})
+    with torch.no_grad():
+        m(x)
+        torch.cuda.synchronize()
+        assert plan.query("range_overflow") == 1
 
 
 def test_valexnet_config5(dev):

@@ -5,7 +5,7 @@ sub = sys.argv[2] if len(sys.argv) > 2 else ""
 acc = collections.defaultdict(lambda: collections.defaultdict(lambda: [0.0, 0]))
 for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        k = r["Kernel_Name"].split("(")[0][:60]
+        k = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("ttnet::", "").split("(")[0][:70]
         if sub in k:
             a = acc[k][r["Counter_Name"]]
             a[0] += float(r["Counter_Value"]); a[1] += 1
