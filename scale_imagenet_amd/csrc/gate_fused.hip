@@ -45,6 +45,13 @@ namespace ttnet {
 
 namespace {
 
+// tools/ubench/fused_phases.hip builds this file with parts switched off (an additive decomposition of
+// the kernel's time): 1 no table streams, 2 no phase A, 4 no phase B, 8 no phase C (bit mask).  0 in the library.
+#ifndef TT_FUSED_SKIP
+#define TT_FUSED_SKIP 0
+#endif
+constexpr int kSkip = TT_FUSED_SKIP;
+
 constexpr int kFT = 1024;              // threads per workgroup: 16 waves, 4 per SIMD
 constexpr int kFBuf = 65536;           // one table buffer
 constexpr int kFMaxScratch = 160 * 1024 - 2 * kFBuf;
@@ -71,6 +78,7 @@ struct FusedArgs {
 };
 
 __device__ inline void dma_table(uint8_t *dst, const uint8_t *src) {
+  if constexpr (kSkip & 1) return;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
   for (int k = 0; k < kFBuf / 1024 / (kFT / 64); ++k) {
@@ -255,6 +263,7 @@ __global__ __launch_bounds__(kFT) void gate_block_kernel(FusedArgs a) {
 
   // ---- phase A: Block_conv3 + the two majority pools -> bytes 2, 3 --------------------------------
   auto phase_a = [&](int rn, const uint8_t *tab) {
+    if constexpr (kSkip & 2) return;
     // zero border of out3 / out4 (ZeroPad2d((1,0,1,0)) at W = 56, (0,1,0,1) otherwise, :98-139)
     const int tid = opaque_tid();
     for (int t = tid; t < rn * (HO + WO - 1); t += kFT) {
@@ -264,24 +273,44 @@ __global__ __launch_bounds__(kFT) void gate_block_kernel(FusedArgs a) {
       *(uint16_t *)((uint8_t *)(S + im * PIX + pix) + 2) = 0;
     }
     const int g = tid >> 4, j = tid & 15;
+    // Four transposes at a time (their LDS round trips overlap): the two rows x two 32-pixel chunks of a
+    // task at W = 56, the two rows of two tasks otherwise.  Unit u of a batch = one (task, chunk).
+    constexpr int CHUNKS = W > 32 ? 2 : 1, TPB = 2 / CHUNKS;          // tasks per batch
+    static_assert(TA % TPB == 0, "phase A walks whole batches");
 #pragma unroll
-    for (int p = 0; p < TA; ++p) {
-      const int gt = p * (kFT / 16) + g;
-      const bool ok = gt < rn * HP;                    // uniform over the 16-lane group
-      const int im = ok ? gt / HP : 0, py = ok ? gt - (gt / HP) * HP : 0;
-      constexpr int CHUNKS = W > 32 ? 2 : 1;
+    for (int bt = 0; bt < TA / TPB; ++bt) {
+      uint32_t d[4];
 #pragma unroll
-      for (int k = 0; k < CHUNKS; ++k) {
-        // lane c holds 32 pixels of channel c in each of the two rows; transposed: lane j holds the
-        // 16-channel words of pixels 32k + j (low half) and 32k + 16 + j (high half)
-        const uint32_t d0 = (uint32_t)((uint64_t)ra[p][0] >> (32 * k)), d1 = (uint32_t)((uint64_t)ra[p][1] >> (32 * k));
-        const uint32_t t0 = transpose16(d0, lk), t1 = transpose16(d1, lk);
+      for (int u = 0; u < 2; ++u) {
+        const int p = bt * TPB + (CHUNKS == 2 ? 0 : u), k = CHUNKS == 2 ? u : 0;
+        d[2 * u] = (uint32_t)((uint64_t)ra[p][0] >> (32 * k));
+        d[2 * u + 1] = (uint32_t)((uint64_t)ra[p][1] >> (32 * k));
+      }
+      // lane c holds 32 pixels of channel c; transposed: lane j holds the 16-channel words of pixels
+      // 32k + j (low half) and 32k + 16 + j (high half)
+      transpose16_multi<4>(d, lk);
+      uint32_t v3[2], v4[2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const uint32_t t0 = d[2 * u], t1 = d[2 * u + 1];
         const uint32_t e00 = tab[t0 & 0xFFFFu], e01 = tab[t0 >> 16], e10 = tab[t1 & 0xFFFFu], e11 = tab[t1 >> 16];
-        const uint32_t v3 = e00 | (e10 << 8) | (e01 << 16) | (e11 << 24);                         // conv3: rows x halves
-        const uint32_t v4 = __builtin_amdgcn_perm(t1, t0, half ? 0x07030501u : 0x06020400u);      // raw input, own byte
-        // the next column's values (lane j + 1); only even lanes produce a pooled pixel
-        const uint32_t n3 = (uint32_t)__builtin_amdgcn_ds_swizzle((int)v3, 0x041F), n4 = (uint32_t)__builtin_amdgcn_ds_swizzle((int)v4, 0x041F);
-        const uint32_t m3 = maj4_bytes(v3, n3), m4 = maj4_bytes(v4, n4);     // (the same in both lanes of a column pair)
+        v3[u] = e00 | (e10 << 8) | (e01 << 16) | (e11 << 24);                                 // conv3: rows x halves
+        v4[u] = __builtin_amdgcn_perm(t1, t0, half ? 0x07030501u : 0x06020400u);              // raw input, own byte
+      }
+      // the next column's values (lane j ^ 1): both lanes of a column pair get the same majorities
+      uint32_t n3[2], n4[2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        n3[u] = lane_xor16<1>(v3[u]);
+        n4[u] = lane_xor16<1>(v4[u]);
+      }
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int p = bt * TPB + (CHUNKS == 2 ? 0 : u), k = CHUNKS == 2 ? u : 0;
+        const int gt = p * (kFT / 16) + g;
+        const bool ok = gt < rn * HP;                    // uniform over the 16-lane group
+        const int im = ok ? gt / HP : 0, py = ok ? gt - (gt / HP) * HP : 0;
+        const uint32_t m3 = maj4_bytes(v3[u], n3[u]), m4 = maj4_bytes(v4[u], n4[u]);
         // the even lane of a pair stores the pooled pixel of the low half, the odd lane that of the high half
         const uint32_t sh = (uint32_t)(j & 1) * 16u;
         const uint32_t t = ((m3 >> sh) & 0xFFu) | (((m4 >> sh) & 0xFFu) << 8);     // nibbles [o4.hi o4.lo o3.hi o3.lo]
@@ -293,68 +322,87 @@ __global__ __launch_bounds__(kFT) void gate_block_kernel(FusedArgs a) {
           const int pix = (py + a.off34) * WO + px + a.off34;
           *(uint16_t *)((uint8_t *)(S + im * PIX + pix) + 2) = (uint16_t)v;
         }
-        __builtin_amdgcn_sched_barrier(0);             // one chunk at a time: keeps the live set small
       }
+      __builtin_amdgcn_sched_barrier(0);               // one batch at a time: keeps the live set small
     }
   };
 
-  // ---- phase B: Block_conv1 + Block_conv2 of four channels -> byte `sub` --------------------------
-  auto phase_b = [&](int rn, const uint8_t *tab, int sub, const TI (&rb)[4]) {
+  // ---- phase B: Block_conv1 + Block_conv2 of four channels -> byte `sub` -----------------------------
+  // B1 only looks up (its two output rows stay in registers); B2 looks up, then transposes all four rows
+  // together and stores bytes 0 and 1 of every pixel as one 16-bit word.
+  uint32_t bacc[2][2];
+  auto phase_b_lookup = [&](const uint8_t *tab, int sub, const TI (&rb)[4]) {
+    if constexpr (kSkip & 4) return;
     const int tid = opaque_tid();
-    const int c4 = tid & 3, j = tid & 15, gi = tid >> 4;
+    dw_row_both<W, WO>(rb, tab, (uint32_t)(tid & 3) * 8u, bacc[sub][0], bacc[sub][1]);
+  };
+  auto phase_b_store = [&](int rn) {
+    if constexpr (kSkip & 4) return;
+    const int tid = opaque_tid();
+    const int j = tid & 15, gi = tid >> 4;
     const int im = gi / RG, rg = gi - im * RG;
-    uint32_t acc1, acc2;
-    dw_row_both<W, WO>(rb, tab, (uint32_t)c4 * 8u, acc1, acc2);
     // 16-lane group = 4 channels x 4 output rows (lane = c + 4 r).  Transposed: lane j holds, for
-    // columns j (low half) and 16 + j (high half), nibble r = channels 0-3 of output row 4 rg + r
-    const uint32_t t1 = transpose16(acc1, lk), t2 = transpose16(acc2, lk);
-    const uint32_t lo = spread_nibbles(t1 & 0xFFFFu) | (spread_nibbles(t2 & 0xFFFFu) << 4);       // byte r: out1 | out2 << 4
-    uint8_t *dst = (uint8_t *)(S + im * PIX + 4 * rg * WO + j) + sub;
-    if (im < rn && j < WO) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-        if (4 * rg + r < HO) dst[r * WO * 4] = (uint8_t)(lo >> (8 * r));
-    }
-    if constexpr (WO > 16) {
-      const uint32_t hi = spread_nibbles(t1 >> 16) | (spread_nibbles(t2 >> 16) << 4);
-      if (im < rn && 16 + j < WO) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-          if (4 * rg + r < HO) dst[(r * WO + 16) * 4] = (uint8_t)(hi >> (8 * r));
+    // columns j (low half) and 16 + j (high half), nibble r = the 4 channels of output row 4 rg + r
+    uint32_t t[4] = {bacc[0][0], bacc[0][1], bacc[1][0], bacc[1][1]};
+    transpose16_multi<4>(t, lk);
+    uint8_t *dst = (uint8_t *)(S + im * PIX + 4 * rg * WO + j);
+    auto put = [&](uint32_t w0, uint32_t w1, int col0) {      // w0 / w1: byte r = (out1 | out2 << 4) of channels 0-3 / 4-7
+      if (im < rn && col0 + j < WO) {
+        const uint32_t lo = __builtin_amdgcn_perm(w1, w0, 0x05010400u), hi = __builtin_amdgcn_perm(w1, w0, 0x07030602u);
+        if (4 * rg + 0 < HO) *(uint16_t *)(dst + (0 * WO + col0) * 4) = (uint16_t)lo;
+        if (4 * rg + 1 < HO) *(uint16_t *)(dst + (1 * WO + col0) * 4) = (uint16_t)(lo >> 16);
+        if (4 * rg + 2 < HO) *(uint16_t *)(dst + (2 * WO + col0) * 4) = (uint16_t)hi;
+        if (4 * rg + 3 < HO) *(uint16_t *)(dst + (3 * WO + col0) * 4) = (uint16_t)(hi >> 16);
       }
-    }
+    };
+    put(spread_nibbles(t[0] & 0xFFFFu) | (spread_nibbles(t[1] & 0xFFFFu) << 4),
+        spread_nibbles(t[2] & 0xFFFFu) | (spread_nibbles(t[3] & 0xFFFFu) << 4), 0);
+    if constexpr (WO > 16)
+      put(spread_nibbles(t[0] >> 16) | (spread_nibbles(t[1] >> 16) << 4), spread_nibbles(t[2] >> 16) | (spread_nibbles(t[3] >> 16) << 4), 16);
   };
 
-  // ---- phase C1: Block_convf group 2s -> byte 0 (in place of the index byte it consumed) ------------
-  auto phase_c1 = [&](int i0, int rn, const uint8_t *tab) {
-    const int tid = opaque_tid();
-    for (int t = tid; t < rn * PIX; t += kFT) {
-      const uint32_t d = S[t];
-      if (a.idx) a.idx[((size_t)(n0 + i0 + t / PIX) * strands + st) * PIX + (t % PIX)] = d;      // parity tap
-      ((uint8_t *)(S + t))[0] = tab[__builtin_amdgcn_perm(0u, d, 0x0C0C0200u)];
-    }
-  };
-
-  // ---- phase C2: Block_convf group 2s+1, then the block's 16 output channels as rows ------------------
-  auto phase_c2 = [&](int i0, int rn, const uint8_t *tab) {
+  // ---- phases C1 / C2: Block_convf group 2s + k -> output channels 16 s + 8 k .. + 7, as rows -----------------
+  // A lane looks up two pixels, the same column in two rows, and carries their bytes as one 16-bit
+  // value; the 16 x 16 transpose of a 16-lane group then leaves channel j of the first row in lane j
+  // and of the second row in lane 8 + j.  A wave task = 2 * RPW row pairs... i.e. 2 * RPW rows x LPR columns.
+  auto phase_c = [&](int i0, int rn, const uint8_t *tab, int kgrp) {
+    if constexpr (kSkip & 8) return;
     const int tid = opaque_tid();
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int sub = lane / LPR, ox = lane % LPR;
     TOut *const y = (TOut *)a.y;
-    for (int wt = wave; wt < rn * CHK; wt += kFT / 64) {
-      const int im = wt / CHK, oy = (wt - im * CHK) * RPW + sub;
-      const bool ok = oy < HO && ox < WO;
-      uint32_t w = 0;
-      if (ok) {
-        const uint32_t d = S[im * PIX + oy * WO + ox];
-        w = (d & 0xFFu) | ((uint32_t)tab[__builtin_amdgcn_perm(0u, d, 0x0C0C0301u)] << 8);
+    constexpr int CH2 = (HO + 2 * RPW - 1) / (2 * RPW);       // wave tasks per image (2 RPW rows each)
+    constexpr int U = 2, NW = kFT / 64;                       // wave tasks per trip
+    const uint32_t sel = kgrp ? 0x0C0C0301u : 0x0C0C0200u;    // index of group k: bytes (k, 2 + k) of the branch dword
+    if (kgrp == 0 && a.idx)                                   // parity tap: the branch dwords as the lookups see them
+      for (int t = tid; t < rn * PIX; t += kFT) a.idx[((size_t)(n0 + i0 + t / PIX) * strands + st) * PIX + (t % PIX)] = S[t];
+    for (int wt0 = wave; wt0 < rn * CH2; wt0 += U * NW) {
+      uint32_t w[U], d0[U], d1[U];
+      int im[U], oy[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int wt = wt0 + u * NW;                          // (wave-uniform)
+        im[u] = wt / CH2;
+        oy[u] = (wt - im[u] * CH2) * 2 * RPW + sub;           // this lane's first row; its second is RPW below
+        const bool live = wt < rn * CH2 && ox < WO;
+        d0[u] = live && oy[u] < HO ? S[im[u] * PIX + oy[u] * WO + ox] : 0u;
+        d1[u] = live && oy[u] + RPW < HO ? S[im[u] * PIX + (oy[u] + RPW) * WO + ox] : 0u;
       }
-      // lane = pixel, bit = channel -> lane j = channel j, bit = pixel of its 16-lane group
-      const uint32_t piece = transpose16(w, lk) & 0xFFFFu;
-      uint32_t rowbits = piece;
-      if constexpr (LPR == 32) rowbits |= (uint32_t)__shfl_xor((int)piece, 16) << 16;
-      if ((lane & (LPR - 1)) < 16 && oy < HO)
-        y[((size_t)(n0 + i0 + im) * (2 * a.C) + 16 * st + (lane & 15)) * HO + oy] = (TOut)rowbits;
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+        w[u] = ox < WO ? (uint32_t)tab[__builtin_amdgcn_perm(0u, d0[u], sel)] | ((uint32_t)tab[__builtin_amdgcn_perm(0u, d1[u], sel)] << 8)
+                       : 0u;                                  // (pixels beyond the row stay zero: the next block's padding)
+      // lane = pixel, bit = (row, channel) -> lane 8 q + j = channel j of row q, bit = pixel of the 16-lane group
+      transpose16_multi<U>(w, lk);
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const uint32_t piece = w[u] & 0xFFFFu;
+        uint32_t rowbits = piece;
+        if constexpr (LPR == 32) rowbits |= (uint32_t)__shfl_xor((int)piece, 16) << 16;
+        const int row = oy[u] + ((lane >> 3) & 1) * RPW;
+        if (wt0 + u * NW < rn * CH2 && (lane & (LPR - 1)) < 16 && row < HO)
+          y[((uint32_t)(n0 + i0 + im[u]) * (uint32_t)(2 * a.C) + 16 * st + 8 * kgrp + (lane & 7)) * HO + row] = (TOut)rowbits;
+      }
     }
   };
 
@@ -366,10 +414,12 @@ __global__ __launch_bounds__(kFT) void gate_block_kernel(FusedArgs a) {
   };
 
   // ---- the pipeline ------------------------------------------------------------------------------------
-  // Every phase boundary is one __syncthreads() (which drains vmcnt and lgkmcnt first): the table of
-  // the phase about to start and its input rows have landed, every wave has left the previous phase
-  // (its table buffer and, after C2, the scratch are free).  Right after it the NEXT phase's rows and
-  // table are requested; the phase then works from registers and LDS only.
+  // Every phase boundary is one phase_sync(): the table of the phase about to start and its input rows
+  // have landed, every wave has left the previous phase (its table buffer and, after C2, the scratch are
+  // free).  Right after it the NEXT phase's rows and table are requested; the phase itself then works
+  // from registers and LDS only.  (Measured alternative: 512-thread workgroups, two per CU, one table
+  // buffer each, the other workgroup computing while one streams -- 28 us instead of 21 for the first
+  // block at B = 256: twice the table bytes per CU, and the L2 -> LDS stream, ~100 GB/s per CU, binds.)
   const int total = n1 - n0;
   int cur = 0;
   load_a(0, min(R, total));
@@ -386,7 +436,7 @@ __global__ __launch_bounds__(kFT) void gate_block_kernel(FusedArgs a) {
     phase_sync();
     load_b(i0, rn, 1, rb1);
     dma_table(nb, src_dw1);
-    phase_b(rn, tb, 0, rb0);
+    phase_b_lookup(tb, 0, rb0);
     cur ^= 1; tb = cur ? buf1 : buf0; nb = cur ? buf0 : buf1;
     phase_sync();
     if constexpr (LAST) {
@@ -394,24 +444,26 @@ __global__ __launch_bounds__(kFT) void gate_block_kernel(FusedArgs a) {
         load_a(i0 + R, min(R, total - i0 - R));
         dma_table(nb, src_c3);
       }
-      phase_b(rn, tb, 1, rb1);
+      phase_b_lookup(tb, 1, rb1);
+      phase_b_store(rn);
       cur ^= 1;
       phase_sync();
       phase_out(i0, rn);
     } else {
       dma_table(nb, src_cf0);
-      phase_b(rn, tb, 1, rb1);
+      phase_b_lookup(tb, 1, rb1);
+      phase_b_store(rn);
       cur ^= 1; tb = cur ? buf1 : buf0; nb = cur ? buf0 : buf1;
       phase_sync();
       dma_table(nb, src_cf1);
-      phase_c1(i0, rn, tb);
+      phase_c(i0, rn, tb, 0);
       cur ^= 1; tb = cur ? buf1 : buf0; nb = cur ? buf0 : buf1;
       phase_sync();
       if (more) {
         load_a(i0 + R, min(R, total - i0 - R));
         dma_table(nb, src_c3);
       }
-      phase_c2(i0, rn, tb);
+      phase_c(i0, rn, tb, 1);
       cur ^= 1;
     }
   }
@@ -496,7 +548,7 @@ int launch_gate_block(const FusedBlockArgs &f, hipStream_t s) {
   }
 #define TT_FUSED_CASE(h, ho)                                                         \
   if (f.H == h && f.Ho == ho) return f.last ? launch_block_t<h, ho, true>(f, s) : launch_block_t<h, ho, false>(f, s)
-  TT_FUSED_CASE(56, 29);
+  if (f.H == 56 && f.Ho == 29 && !f.last) return launch_block_t<56, 29, false>(f, s);     // (the first block is never the last)
   TT_FUSED_CASE(29, 15);
   TT_FUSED_CASE(15, 8);
   TT_FUSED_CASE(8, 5);

@@ -113,6 +113,35 @@ __device__ inline uint32_t transpose16(uint32_t acc, const DwLaneConst &k) {
   return acc;
 }
 
+// The value of lane (l ^ S) within each row of 16 lanes, by DPP (a VALU move: no trip through the LDS
+// crossbar, whose issue rate -- shared by the four SIMDs of a CU -- bounds kernels that transpose a lot)
+template <int S>
+__device__ inline uint32_t lane_xor16(uint32_t v) {
+  static_assert(S == 8 || S == 4 || S == 2 || S == 1, "butterfly distances");
+  if constexpr (S == 8) return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x128, 0xF, 0xF, true);           // row_ror:8
+  else if constexpr (S == 4)                                                                              // l ^ 7, then l ^ 3
+    return (uint32_t)__builtin_amdgcn_mov_dpp(__builtin_amdgcn_mov_dpp((int)v, 0x141, 0xF, 0xF, true), 0x1B, 0xF, 0xF, true);
+  else if constexpr (S == 2) return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x4E, 0xF, 0xF, true);      // quad_perm [2,3,0,1]
+  else return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xF, 0xF, true);                            // quad_perm [1,0,3,2]
+}
+
+// N independent 16x16 bit transposes (both 16-bit halves of each register), stage by stage, exchanges by DPP
+template <int N>
+__device__ inline void transpose16_multi(uint32_t (&acc)[N], const DwLaneConst &k) {
+  constexpr int S[4] = {8, 4, 2, 1};
+  static_for<0, 4>([&](auto i) {
+    constexpr int I = decltype(i)::value;
+    uint32_t partner[N];
+#pragma unroll
+    for (int n = 0; n < N; ++n) partner[n] = lane_xor16<S[I]>(acc[n]);
+#pragma unroll
+    for (int n = 0; n < N; ++n) {
+      const uint32_t moved = __builtin_amdgcn_alignbit(partner[n], partner[n], k.rot[I]);
+      acc[n] = moved ^ ((moved ^ acc[n]) & k.keep[I]);
+    }
+  });
+}
+
 #endif
 
 // Raise a kernel's dynamic LDS limit (> 64 KiB) once per kernel and process: the attribute call
