@@ -7,8 +7,9 @@
 // (lut_build.hip), so "the bit" means the same thing for every variant and is independent of
 // summation order (float32 re-ordering was measured to flip outputs).
 //
-// Everything stays on row-packed planes (uint64 per image row).  Bound: fp64 VALU
-// (~0.8 GFLOP per image); this first version is written for parity, not speed.
+// Everything stays on row-packed planes (uint64 per image row).  Bound: the float64 matrix pipe
+// (0.72 GFLOP per image in the two grouped convolutions of the 1x1 blocks: 4.7 ms per 512 images at
+// the 78.6 TFLOP/s FP64 peak) plus the GELU (a branch-free table erf, see gelu_exact).
 
 #include <cstdlib>
 
@@ -18,12 +19,38 @@ namespace ttnet {
 
 namespace {
 
-__device__ inline double gelu_exact(double x) { return 0.5 * x * (1.0 + erf(x * 0.70710678118654752440)); }
+// erf in float64 without branches: libm's erf picks one of five range-dependent algorithms per lane, so
+// a wave executes all of them (108 vector instructions per call, and the full model calls it 7.6 M times
+// per image: it was most of the variant's time).  Here: 48 intervals of width 1/8 on [0, 6), the degree-8
+// Chebyshev-node interpolant per interval (tools/gen_erf_table.py, mpmath at 60 digits; max abs error
+// 3.3e-16 against mpmath's erf, i.e. as exact as libm's), evaluated with 8 FMAs from a 3.4 KiB LDS copy
+// of the table.  erf(x) rounds to 1.0 for x >= 6.
+constexpr int kErfN = 48, kErfC = 9;
+__device__ const double kErfTable[kErfN][kErfC] = {
+#include "erf_table.inc"
+};
+__device__ inline void erf_table_to_lds(double *dst) {
+  for (int i = threadIdx.x; i < kErfN * kErfC; i += blockDim.x) dst[i] = (&kErfTable[0][0])[i];
+}
+__device__ inline double gelu_exact(double z, const double *tab) {
+  const double x = z * 0.70710678118654752440, ax = __builtin_fabs(x);
+  int i = (int)(ax * 8.0);
+  i = i < kErfN - 1 ? i : kErfN - 1;
+  const double t = ax - ((double)i + 0.5) * 0.125;
+  const double *c = tab + i * kErfC;
+  double p = c[8];
+#pragma unroll
+  for (int k = 7; k >= 0; --k) p = fma(p, t, c[k]);
+  p = ax >= 6.0 ? 1.0 : p;
+  return 0.5 * z * (1.0 + __builtin_copysign(p, x));
+}
 
 // ---- depthwise Block_TT: one input channel -> 8 mid -> 1 output ---------------------------------
 // grid (C, n-chunks); thread = (image, output row); weights of the channel in LDS.
 __global__ __launch_bounds__(256) void full_dw_kernel(FullDwArgs a) {
   __shared__ double w1[8 * 36], s1[8], t1[8], w2[8], s2, t2;
+  __shared__ double erf_tab[kErfN * kErfC];
+  erf_table_to_lds(erf_tab);
   const int c = blockIdx.x, nk = a.kh * a.kw;
   for (int i = threadIdx.x; i < 8 * nk; i += blockDim.x) w1[i] = (double)a.w1[(size_t)c * 8 * nk + i];
   if (threadIdx.x < 8) {
@@ -53,7 +80,7 @@ __global__ __launch_bounds__(256) void full_dw_kernel(FullDwArgs a) {
           const uint32_t bits = (uint32_t)(r[kh] >> (ox * a.stride));
           for (int kw = 0; kw < a.kw; ++kw) s += ((bits >> kw) & 1u) ? w1[m * nk + kh * a.kw + kw] : 0.0;
         }
-        acc = fma(gelu_exact(s * s1[m] + t1[m]), w2[m], acc);
+        acc = fma(gelu_exact(s * s1[m] + t1[m], erf_tab), w2[m], acc);
       }
       const double pre = acc * s2 + t2;
       out |= (uint64_t)(pre >= 0.0) << (ox + a.pad_l);
@@ -72,6 +99,8 @@ template <int KH, int KW>
 __global__ __launch_bounds__(256) void full_dw_tab_kernel(FullDwArgs a) {
   __shared__ double tab[8][KH][1 << KW];
   __shared__ double s1[8], t1[8], w2[8], s2, t2;
+  __shared__ double erf_tab[kErfN * kErfC];
+  erf_table_to_lds(erf_tab);
   const int c = blockIdx.x;
   constexpr int nk = KH * KW;
   for (int i = threadIdx.x; i < 8 * KH * (1 << KW); i += blockDim.x) {
@@ -111,7 +140,7 @@ __global__ __launch_bounds__(256) void full_dw_tab_kernel(FullDwArgs a) {
         double sm = tab[m][0][idx[0]];
 #pragma unroll
         for (int kh = 1; kh < KH; ++kh) sm += tab[m][kh][idx[kh]];
-        acc = fma(gelu_exact(sm * s1[m] + t1[m]), w2[m], acc);
+        acc = fma(gelu_exact(sm * s1[m] + t1[m], erf_tab), w2[m], acc);
       }
       const double pre = acc * s2 + t2;
       out |= (uint64_t)(pre >= 0.0) << (ox + a.pad_l);
@@ -131,6 +160,8 @@ __global__ __launch_bounds__(256) void full_dw_tab_kernel(FullDwArgs a) {
 // (Compile-time sizes with full unrolling were tried and were slower: more registers, same reads.)
 __global__ __launch_bounds__(1024) void full_pw_kernel(FullPwArgs a) {
   extern __shared__ __align__(16) double lds[];
+  __shared__ double erf_tab[kErfN * kErfC];
+  erf_table_to_lds(erf_tab);
   const int g = blockIdx.x, cin = a.cin, mid = a.mid, cout = a.cout;
   double *w1 = lds;                      // [mid][cin]
   double *w2 = w1 + mid * cin;           // [cout][mid]
@@ -173,7 +204,7 @@ __global__ __launch_bounds__(1024) void full_pw_kernel(FullPwArgs a) {
       double s = 0.0;
       const double *wr = w1 + m * cin;
       for (int j = 0; j < cin; ++j) s += ((in >> j) & 1u) ? wr[j] : 0.0;
-      const double h = gelu_exact(s * s1[m] + t1[m]);
+      const double h = gelu_exact(s * s1[m] + t1[m], erf_tab);
 #pragma unroll
       for (int o = 0; o < 30; ++o)
         if (o < cout) acc[o] = fma(h, w2[o * mid + m], acc[o]);
@@ -209,6 +240,8 @@ typedef double f64x4 __attribute__((ext_vector_type(4)));
 template <int OT>      // 16-row output tiles: 2 (cout = 30) or 1 (cout = 15)
 __global__ __launch_bounds__(512) void full_pw_mfma_kernel(FullPwArgs a) {
   extern __shared__ __align__(16) double lds[];
+  __shared__ double erf_tab[kErfN * kErfC];
+  erf_table_to_lds(erf_tab);
   constexpr int CIN = 30, MT = 15, KS1 = 8;              // 240 hidden units, K = 30 padded to 32
   double *w1f = lds;                                     // [MT][KS1][64]
   double *w2f = w1f + MT * KS1 * 64;                     // [MT][4][OT][64]
@@ -274,7 +307,7 @@ __global__ __launch_bounds__(512) void full_pw_mfma_kernel(FullPwArgs a) {
         const double sc = s1[16 * mt + 4 * i + lg], sh = t1[16 * mt + 4 * i + lg];
         double h[4];
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt) h[nt] = gelu_exact(d[nt][i] * sc + sh);
+        for (int nt = 0; nt < 4; ++nt) h[nt] = gelu_exact(d[nt][i] * sc + sh, erf_tab);
 #pragma unroll
         for (int ot = 0; ot < OT; ++ot) {
           const double wb = w2f[((mt * 4 + i) * OT + ot) * 64 + lane];

@@ -41,7 +41,7 @@ constexpr int G_MT = G_BM / 32, G_NT = G_BN / 32;
 constexpr int G_KS = 1;                               // k-steps (of 16) per LDS stage
 constexpr int G_CHUNK = 1024;                         // one fragment block: 64 lanes x 16 B
 constexpr int G_STAGE = (G_MT + G_NT) * G_KS * NP * G_CHUNK;  // 24 KiB
-constexpr int G_STAGES = 4;                           // LDS ring: 3 stages in flight behind the one being read
+constexpr int G_STAGES = 4;                           // LDS ring: 3 stages in flight behind the one being read (6 stages: no faster)
 constexpr int G_WAVES = 8;                            // two waves per SIMD: one wave's LDS reads / waits hide behind the other's MFMAs
 constexpr int G_CHUNKS = (G_MT + G_NT) * G_KS * NP;   // 24 fragment blocks per stage
 constexpr int G_LOADS = (G_CHUNKS + G_WAVES - 1) / G_WAVES;   // direct-to-LDS loads per wave and stage (3; any
@@ -117,7 +117,10 @@ __global__ __launch_bounds__(64 * G_WAVES) void gemm_f16x2_kernel(const uint8_t 
   for (int p = 0; p < G_STAGES - 1 && p < iters; ++p) issue(p, p);
   for (int it = 0; it < iters; ++it) {
     const int younger = min(G_STAGES - 2, iters - 1 - it);       // stages issued after stage `it`
-    if (younger >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * G_LOADS) : "memory");
+    static_assert(G_STAGES <= 6, "one s_waitcnt per possible count of younger stages");
+    if (younger >= 4) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * G_LOADS) : "memory");
+    else if (younger == 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * G_LOADS) : "memory");
+    else if (younger == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * G_LOADS) : "memory");
     else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G_LOADS) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");

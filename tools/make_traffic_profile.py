@@ -12,6 +12,10 @@ import csv, glob, json, os, sys, collections
 LABELS = [  # (substring of the kernel name, bench.py label, wide-stream correction)
     ("stem_pc_kernel", "stem", True), ("gate_last", "gate_last", True), ("gemm_f16x2_kernel", "head.lin1", True),
     ("lin2_f16x2_kernel", "head.lin2", True), ("head_mid_kernel", "head.bn_poly", False),
+    # block-fused gate path (round 2): rows in as 8 / 4 / 2-byte words per lane, tables as 16-byte LDS-DMA streams
+    ("gate_block_kernel<56, 29", "gate_block.f4", False), ("gate_block_kernel<29, 15", "gate_block.f5", False),
+    ("gate_block_kernel<15, 8", "gate_block.f6", False), ("gate_block_kernel<8, 5", "gate_block.f7", False),
+    # two-launch gate path (TTNET_GATE_UNFUSED=1, and the stride-1 blocks of --layers 3 / 4)
     ("gate_stage1_kernel<4, 4, 2, 2, 56, 29>", "gate_stage1.f4", False), ("gate_stage1_kernel<4, 4, 2, 2, 29, 15>", "gate_stage1.f5", False),
     ("gate_stage1_kernel<4, 4, 2, 2, 15, 8>", "gate_stage1.f6", False), ("gate_pf_kernel<29, 8>", "gate_pf.f4", False),
     ("gate_pf_kernel<15, 8>", "gate_pf.f5", False),
