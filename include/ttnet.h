@@ -131,6 +131,19 @@ int ttnet_forward_lane(ttnet_plan *plan, int lane, const float *x_dev, int64_t n
 int ttnet_plan_set_input_norm(ttnet_plan *plan, const float *mean3, const float *std3);
 int ttnet_forward_u8(ttnet_plan *plan, int lane, const uint8_t *x_nhwc_dev, int64_t n, float *logits_dev, void *stream);
 
+/* SURVEY 8(f) N1, the part in front of ttnet_forward_u8: transforms.Resize(resize) followed by
+ * transforms.CenterCrop(crop) of the eval transform (utils/preprocess.py:104-105; 256 / 224 there) on a batch of
+ * n decoded images of one size, uint8 HWC [n][h][w][3] -> uint8 [n][crop][crop][3], both on the device.
+ * Resize is torchvision's resize of a PIL image, i.e. Pillow's bilinear resampling with antialiasing in
+ * 8-bit fixed point (horizontal pass, then vertical); the output size and crop offsets follow
+ * torchvision.transforms.functional (shorter side -> resize, longer side int(resize * long / short);
+ * offsets int(round((size - crop) / 2.0))).  Not bound to a plan.  Synchronises `stream` before returning
+ * (it frees its scratch).  Parity with Pillow itself is UNPINNED here (Pillow / torchvision are not
+ * importable where this is built and tested): the kernels are checked against a numpy restatement of
+ * the published algorithm (oracle/pil_resize.py). */
+int ttnet_resize_center_crop_u8(const uint8_t *src_hwc_dev, int64_t n, int h, int w, int resize, int crop,
+                                uint8_t *dst_hwc_dev, void *stream);
+
 /* Same, starting from the binarised stem output (features[3], netbin.py:193) given as
  * row-packed bits uint64 [n][p][56]; used by the parity tests to separate the integer
  * gate path (bit exact) from the float stem (exact except at near ties). */

@@ -40,6 +40,7 @@ SYMBOLS: List[Tuple[str, object, list]] = [
     ("ttnet_forward_lane", C.c_int, [_P, C.c_int, _P, C.c_int64, _P, _P]),
     ("ttnet_plan_set_input_norm", C.c_int, [_P, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     ("ttnet_forward_u8", C.c_int, [_P, C.c_int, _P, C.c_int64, _P, _P]),
+    ("ttnet_resize_center_crop_u8", C.c_int, [_P, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P]),
     ("ttnet_forward_from_stem_bits", C.c_int, [_P, _P, C.c_int64, _P, _P]),
     ("ttnet_read_stage", C.c_int, [_P, C.c_char_p, C.c_int64, _P, C.c_size_t, C.c_int, _P]),
     ("ttnet_plan_get_table", C.c_int, [_P, C.c_char_p, _P, C.c_size_t]),

@@ -13,7 +13,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libttnet.so")
-SOURCES = ["plan.hip", "lut_build.hip", "stem.hip", "gate.hip", "gate_fused.hip", "gate_xs.hip", "gate_full.hip", "gate_va.hip", "head.hip"]
+SOURCES = ["plan.hip", "lut_build.hip", "stem.hip", "gate.hip", "gate_fused.hip", "gate_xs.hip", "gate_full.hip", "gate_va.hip", "head.hip", "preproc.hip"]
 FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function",
          "-ffp-contract=off"]
 
