@@ -584,6 +584,10 @@ def test_other_depths_against_the_oracle(dev, layers):
     bits = OB.unpack_rows(stem_rows, 56)
     # 1. tables: GPU float64 == numpy float64 (differences only where the oracle itself sees a near tie)
     luts = {}
+    from concurrent.futures import ThreadPoolExecutor      # (numpy / scipy release the GIL: ~100 s of table building otherwise)
+    with ThreadPoolExecutor(max_workers=8) as ex:
+        built = dict(zip([b.name for b in spec.block_tts() if not b.last],
+                         ex.map(lambda b: OB.build_lut(st, b), [b for b in spec.block_tts() if not b.last])))
     for b in spec.block_tts():
         tab = m.get_table(b.name)
         if b.last:
@@ -592,7 +596,7 @@ def test_other_depths_against_the_oracle(dev, layers):
             assert np.abs(tab[gl] - ref).max() <= 1e-6, b.name
             luts[b.name] = tab                      # (the remaining groups are exercised through check 2's logits)
             continue
-        ref, near = OB.build_lut(st, b)
+        ref, near = built[b.name]
         d = np.argwhere(ref != tab)
         assert near[tuple(d.T)].all(), f"--layers {layers} {b.name}: table differs outside the near-tie set"
         luts[b.name] = ref
