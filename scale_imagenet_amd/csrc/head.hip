@@ -36,6 +36,13 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 constexpr int NP = SPLIT_PLANES;
 
+// tools/ubench/lin1_parts.hip builds this file with parts of the GEMM switched off (bit mask: 1 no A stream,
+// 2 no B stream, 4 no MFMAs, 8 no slab stores).  0 in the library.
+#ifndef TT_LIN1_SKIP
+#define TT_LIN1_SKIP 0
+#endif
+constexpr int kLin1Skip = TT_LIN1_SKIP;
+
 constexpr int G_BM = 256, G_BN = 128;                 // workgroup tile: 8 x 4 MFMA tiles of 32x32
 constexpr int G_MT = G_BM / 32, G_NT = G_BN / 32;
 constexpr int G_KS = 1;                               // k-steps (of 16) per LDS stage
@@ -49,7 +56,7 @@ constexpr int G_LOADS = (G_CHUNKS + G_WAVES - 1) / G_WAVES;   // direct-to-LDS l
                                                       // surplus slots load into a scratch block so every wave counts the same)
 constexpr int G_LDS = G_STAGES * G_STAGE + G_CHUNK;
 
-// Af: [mtile32][KS][NP][64][8] fp16, Bf: [ntile32][KS][NP][64][8] fp16, part: [splits][M][N] f32
+// Af: [mtile32][KS][NP][64][8] fp16, Bf: [ntile32][KS][NP][64][8] fp16, part: slabs in accumulator order (epilogue)
 __global__ __launch_bounds__(64 * G_WAVES) void gemm_f16x2_kernel(const uint8_t *__restrict__ Af, const uint8_t *__restrict__ Bf,
                                                          float *__restrict__ part, int M, int N, int KS, int ks_per,
                                                          int n_tiles, int m_tiles, int splits) {
@@ -95,11 +102,16 @@ __global__ __launch_bounds__(64 * G_WAVES) void gemm_f16x2_kernel(const uint8_t 
   }
   auto issue = [&](int it, int buf) {
 #pragma unroll
-    for (int jj = 0; jj < G_LOADS; ++jj)
+    for (int jj = 0; jj < G_LOADS; ++jj) {
+      if constexpr (kLin1Skip & 3) {
+        const bool isA = wave + G_WAVES * jj < G_MT * G_KS * NP;
+        if (((kLin1Skip & 1) && isA) || ((kLin1Skip & 2) && !isA)) continue;
+      }
       __builtin_amdgcn_global_load_lds(
           (const __attribute__((address_space(1))) void *)(chunk_src[jj] + (size_t)it * (G_KS * NP * G_CHUNK)),
           (__attribute__((address_space(3))) void *)(lds + (chunk_lds[jj] >= 0 ? buf * G_STAGE + chunk_lds[jj] : G_STAGES * G_STAGE)),
           16, 0, 0);
+    }
   };
 
   constexpr int MPW = G_MT / G_WAVES;                   // M-tiles per wave (1)
@@ -143,6 +155,11 @@ __global__ __launch_bounds__(64 * G_WAVES) void gemm_f16x2_kernel(const uint8_t 
           b[j][pl] = *(const f16x8 *)(st + ((G_MT * G_KS * NP + (j * G_KS + kk) * NP + pl) * G_CHUNK) + lane * 16);
       // the three products of a tile go to the same accumulator: issue them tile-interleaved, so that
       // consecutive MFMAs are independent (same per-accumulator order: low terms first)
+      if constexpr (kLin1Skip & 4) {
+#pragma unroll
+        for (int j = 0; j < G_NT; ++j) acc[0][j][0] += (float)a[0][0][0] + (float)b[j][0][0];      // keep the fragment reads alive
+        continue;
+      }
 #pragma unroll
       for (int i = 0; i < MPW; ++i) {
 #pragma unroll
@@ -154,17 +171,21 @@ __global__ __launch_bounds__(64 * G_WAVES) void gemm_f16x2_kernel(const uint8_t 
       }
     }
   }
+  // The partial tile goes out as the accumulators stand -- slab layout [slice][tile32 row][tile32 col][reg / 4][lane][4]
+  // -- so that a wave's store is one linear 1 KiB block of 16 bytes per lane (row-major slabs took sixteen
+  // 4-byte stores per tile and lane: 8 of the kernel's 45 us at B = 256 were store issue).  Rows / columns of the
+  // padding (M to 256, N to 128) are written too; head_mid_kernel reads the same order and drops them.
   // C/D layout: col = lane&31 (N), row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) (M)
-  float *dst = part + (size_t)slice * M * N;
+  float4 *dst = (float4 *)part + (size_t)slice * (m_tiles * G_MT) * (n_tiles * G_NT) * 256;
 #pragma unroll
   for (int i = 0; i < MPW; ++i)
 #pragma unroll
     for (int j = 0; j < G_NT; ++j) {
-      const int col = (nt0 + j) * 32 + (lane & 31);
+      float4 *tile = dst + ((size_t)(mt0 + MPW * wave + i) * (n_tiles * G_NT) + nt0 + j) * 256 + lane;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = (mt0 + MPW * wave + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        if (row < M && col < N) dst[(size_t)row * N + col] = acc[i][j][r];
+      for (int g = 0; g < 4; ++g) {
+        if ((kLin1Skip & 8) && g) continue;
+        tile[g * 64] = make_float4(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
       }
     }
 }
@@ -200,22 +221,36 @@ __global__ void frag_to_ref_kernel(const uint16_t *__restrict__ af, float *__res
 
 // sum of lin1's K-slices (fixed order) -> BatchNorm1d -> polynomial -> lin2's A operand
 // (fragment order, KS2 = ceil(N/16) k-steps; the k padding stays zero from allocation)
-__global__ void head_mid_kernel(const float *__restrict__ part, int splits, const float *__restrict__ scale,
+// part: lin1's slabs in accumulator order [slice][mt32][nt32][reg / 4][lane][4] (gemm_f16x2_kernel's epilogue); a
+// thread owns one (tile, reg / 4, lane) = four rows of one column and reads 16 bytes per slice
+__global__ void head_mid_kernel(const float4 *__restrict__ part, int splits, const float *__restrict__ scale,
                                 const float *__restrict__ shift, uint16_t *__restrict__ mid_frag, int M, int N,
-                                int polynomial, uint32_t *range_flag) {
+                                int polynomial, uint32_t *range_flag, int mt32, int nt32) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= (size_t)M * N) return;
-  const int nidx = i % N, row = i / N;
-  double s = 0.0;
+  const size_t per_slice = (size_t)mt32 * nt32 * 256;
+  if (i >= per_slice) return;
+  const int lane = i & 63, g = (i >> 6) & 3;
+  const int nt = (int)((i >> 8) % nt32), mt = (int)((i >> 8) / nt32);
+  const int col = nt * 32 + (lane & 31), row0 = mt * 32 + 8 * g + 4 * (lane >> 5);
+  if (col >= N || row0 >= M) return;
+  double s[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll 8
-  for (int z = 0; z < splits; ++z) s += (double)part[(size_t)z * M * N + i];      // fixed order: reproducible
-  float y = fmaf((float)s, scale[nidx], shift[nidx]);
-  if (polynomial) {                      // vAlexnet's Classifier_scale has no activation (:671-675)
-    // 0.47 + 0.50 * x + 0.09 * x ** 2, evaluated left to right in fp32 like the reference
-    const float t = __fadd_rn(0.47f, __fmul_rn(0.50f, y));
-    y = __fadd_rn(t, __fmul_rn(0.09f, __fmul_rn(y, y)));
+  for (int z = 0; z < splits; ++z) {     // fixed order: reproducible
+    const float4 v = part[(size_t)z * per_slice + i];
+    s[0] += (double)v.x; s[1] += (double)v.y; s[2] += (double)v.z; s[3] += (double)v.w;
   }
-  store_feature(mid_frag, row, (N + 15) / 16, nidx >> 4, nidx & 15, y, range_flag);
+  const float sc = scale[col], sh = shift[col];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    if (row0 + e >= M) break;
+    float y = fmaf((float)s[e], sc, sh);
+    if (polynomial) {                    // vAlexnet's Classifier_scale has no activation (:671-675)
+      // 0.47 + 0.50 * x + 0.09 * x ** 2, evaluated left to right in fp32 like the reference
+      const float t = __fadd_rn(0.47f, __fmul_rn(0.50f, y));
+      y = __fadd_rn(t, __fmul_rn(0.09f, __fmul_rn(y, y)));
+    }
+    store_feature(mid_frag, row0 + e, (N + 15) / 16, col >> 4, col & 15, y, range_flag);
+  }
 }
 
 // ---- lin2: out[M][N] = A[M][K] * B[N][K]^T * inv + bias, split operands in fragment order ----
@@ -294,6 +329,11 @@ int gemm_f16x2_splits(int M, int N, int KS) {
   return 1;
 }
 
+size_t gemm_f16x2_part_elems(int M, int N, int KS) {
+  const size_t mt = (M + G_BM - 1) / G_BM, nt = (N + G_BN - 1) / G_BN;
+  return (size_t)gemm_f16x2_splits(M, N, KS) * mt * G_BM * nt * G_BN;
+}
+
 int launch_gemm_f16x2(const void *Af, const void *Bf, float *part, int M, int N, int K, int splits, hipStream_t s) {
   const int KS = K / 16;
   if (K % 16 || KS % splits || (KS / splits) % G_KS) {
@@ -344,9 +384,10 @@ int launch_frag_to_reference_order(const void *af, float *out, int n, int G, int
 
 int launch_head_mid(const float *part, int splits, const float *scale, const float *shift, void *mid_frag, int M, int N,
                     int polynomial, uint32_t *range_flag, hipStream_t s) {
-  const size_t t = (size_t)M * N;
-  hipLaunchKernelGGL(head_mid_kernel, dim3((unsigned)((t + 255) / 256)), dim3(256), 0, s, part, splits, scale, shift,
-                     (uint16_t *)mid_frag, M, N, polynomial, range_flag);
+  const int mt32 = (M + G_BM - 1) / G_BM * G_MT, nt32 = (N + G_BN - 1) / G_BN * G_NT;       // the slabs' padded tile grid
+  const size_t t = (size_t)mt32 * nt32 * 256;
+  hipLaunchKernelGGL(head_mid_kernel, dim3((unsigned)((t + 255) / 256)), dim3(256), 0, s, (const float4 *)part, splits, scale, shift,
+                     (uint16_t *)mid_frag, M, N, polynomial, range_flag, mt32, nt32);
   TT_HIP(hipGetLastError());
   return TTNET_OK;
 }

@@ -483,7 +483,8 @@ int alloc_workspace(ttnet_plan *pl) {
   TT_TRY(dev_alloc(pl, &pl->feat, frag_elems(nb_pad, pl->fcsize), true, ws));
   TT_TRY(dev_alloc(pl, &pl->mid_frag, frag_elems((nb + 63) / 64 * 64, kpad), true, ws));
   size_t pe = 0;
-  for (int n = 1; n <= nb; ++n) pe = std::max(pe, (size_t)gemm_f16x2_splits(n, pl->inter, pl->fcsize / 16) * n * pl->inter);
+  for (int n = 1; n <= nb; n = n < 256 ? 256 : n + 256) pe = std::max(pe, gemm_f16x2_part_elems(std::min(n, nb), pl->inter, pl->fcsize / 16));
+  pe = std::max(pe, gemm_f16x2_part_elems(nb, pl->inter, pl->fcsize / 16));
   pl->part_elems = pe;
   TT_TRY(dev_alloc(pl, &pl->part, pe, false, ws));
   return TTNET_OK;

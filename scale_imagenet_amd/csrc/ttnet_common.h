@@ -303,8 +303,9 @@ int launch_cp_to_rp(const uint16_t *cp, uint64_t *rp, int n, int C, int H, int W
 int launch_rp_to_cp(const uint64_t *rp, uint16_t *cp, int n, int C, int H, int W, hipStream_t s);
 // feature planes (fragment order) -> float32 [n][(16g+k)*PP + pp] (reference Flatten order)
 int launch_frag_to_reference_order(const void *af, float *out, int n, int G, int PP, hipStream_t s);
-// fp16 x 2 split GEMM on fragment-ordered operands: part[splits][M][N]
+// fp16 x 2 split GEMM on fragment-ordered operands: part = split-K slabs in accumulator order (head.hip)
 int gemm_f16x2_splits(int M, int N, int KS);
+size_t gemm_f16x2_part_elems(int M, int N, int KS);      // float32 elements of the split-K slabs (padded tile grid)
 int launch_gemm_f16x2(const void *Af, const void *Bf, float *part, int M, int N, int K, int splits, hipStream_t s);
 size_t frag_elems(int rows, int K);
 // src [R][ld] (ld = 0: K) -> split planes with K (a multiple of 16) columns, columns >= kvalid (0: K) zero
