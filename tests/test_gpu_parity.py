@@ -309,6 +309,31 @@ def test_full_batch_properties(small_model, dev, oracle_small_rows):
     assert len(set(y1.argmax(1).tolist())) > 20          # the synthetic classifier is not degenerate
 
 
+def test_large_batch_rounds_equal_small_batches(dev):
+    """Batches large enough that a workgroup of the block-fused gate kernel walks several rounds (more images
+    per workgroup than its LDS scratch holds: 600 images = 19 per workgroup of the first block, rounds of 8,
+    the last one partial) must give exactly the bits and logits of the same images run 200 at a time."""
+    spec, st = spec_and_state("small")
+    m = ttnet.TT_vf_19lv3_imgnet_small(args_for("small"))
+    m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in st.items()})
+    m = m.to(dev).eval().reserve(600)
+    base = torch.from_numpy(synth.synth_images(200)).to(dev)
+    x = torch.cat([base, base.flip(0), base.roll(7, 0)])          # 600 images, every one a known image
+    with torch.no_grad():
+        y = m(x).clone()
+        s4 = m.read_stage("features.4", 600).copy()
+        s5 = m.read_stage("features.5", 600).copy()
+        o3 = m.read_stage("features.6.out3", 600).copy()
+        ya = m(base).clone()
+        a4 = m.read_stage("features.4", 200).copy()
+        a5 = m.read_stage("features.5", 200).copy()
+        b3 = m.read_stage("features.6.out3", 200).copy()
+    assert torch.equal(y[:200], ya) and torch.equal(y[200:400], ya.flip(0)) and torch.equal(y[400:], ya.roll(7, 0))
+    assert np.array_equal(s4[:200], a4) and np.array_equal(s4[200:400], a4[::-1]) and np.array_equal(s4[400:], np.roll(a4, 7, 0))
+    assert np.array_equal(s5[:200], a5) and np.array_equal(s5[400:], np.roll(a5, 7, 0))
+    assert np.array_equal(o3[:200], b3) and np.array_equal(o3[200:400], b3[::-1])
+
+
 def test_graph_replay_matches_plain_launches(small_model, dev):
     """From the third forward with one batch size the C ABI replays a captured hipGraph; the
     replay must equal the plain launches bit for bit, with fresh input / output buffers."""
