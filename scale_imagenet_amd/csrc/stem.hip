@@ -82,7 +82,10 @@ constexpr int UPW = (UNITS + CONS_WAVES - 1) / CONS_WAVES;   // units per consum
 // split values  ((s/4)/255 - mean_c)/std_c x prescale  built on the host in float64.  A quarter of
 // the input bytes, fewer vector instructions; the value is the real-arithmetic one rounded once
 // (the float32 path rounds each pixel and each add: <= 2e-7 apart on a pooled value).
-template <bool U8>
+// CP = also emit the channel-word layout (read only by the two-launch gate kernels of gate.hip: --layers 3 / 4,
+// x-small, TTNET_GATE_UNFUSED); the block-fused gate path reads rows alone, and the word formation and its
+// cross-lane exchange are then compiled out of the epilogue.
+template <bool U8, bool CP>
 __global__ __launch_bounds__(STEM_THREADS) void stem_pc_kernel(const void *__restrict__ xin, const uint4 *__restrict__ wfrag,
                                                                const float *__restrict__ init, uint64_t *__restrict__ rp,
                                                                uint16_t *__restrict__ cp, int p, int n_images,
@@ -335,13 +338,15 @@ __global__ __launch_bounds__(STEM_THREADS) void stem_pc_kernel(const void *__res
         neg = __builtin_amdgcn_alignbit(neg, __float_as_uint(acc[i][r]), 31);
       });
       const uint32_t bits = ~neg & 0xFFFFu;  // bit r = (acc[r] >= 0)
-      // channel word bit of register r: (r&3) + 8*((r>>2)&1) + 4*h within the 16-channel group r>>3
-      const uint32_t cw0 = bits & 0xFFu, cw1 = bits >> 8;
-      uint32_t pw = ((cw0 & 15u) | ((cw0 & 0xF0u) << 4)) | (((cw1 & 15u) | ((cw1 & 0xF0u) << 4)) << 16);
-      pw <<= 4 * h;
-      pw |= (uint32_t)__shfl_xor((int)pw, 32);
-      const int q = 2 * m + h;               // half-wave 0 stores group 2m, half-wave 1 group 2m+1
-      if (cp) cp[((size_t)n * 4 + q) * (56 * 56) + oy0 * 56 + cpoff[i]] = (uint16_t)(h ? (pw >> 16) : pw);
+      if constexpr (CP) {
+        // channel word bit of register r: (r&3) + 8*((r>>2)&1) + 4*h within the 16-channel group r>>3
+        const uint32_t cw0 = bits & 0xFFu, cw1 = bits >> 8;
+        uint32_t pw = ((cw0 & 15u) | ((cw0 & 0xF0u) << 4)) | (((cw1 & 15u) | ((cw1 & 0xF0u) << 4)) << 16);
+        pw <<= 4 * h;
+        pw |= (uint32_t)__shfl_xor((int)pw, 32);
+        const int q = 2 * m + h;             // half-wave 0 stores group 2m, half-wave 1 group 2m+1
+        cp[((size_t)n * 4 + q) * (56 * 56) + oy0 * 56 + cpoff[i]] = (uint16_t)(h ? (pw >> 16) : pw);
+      }
       // row-word pieces: lane j of a 16-lane group = register j over the group's 16 pixels
       const uint32_t piece = transpose16(bits, tk) & 0xFFFFu;
       const uint32_t other = (uint32_t)__shfl_xor((int)piece, 16);
@@ -456,15 +461,14 @@ int launch_stem(const void *x, bool x_is_u8, const uint32_t *norm_tab, const voi
   const size_t lds = (size_t)2 * TILE * 2 + (size_t)2 * 64 * (NT + 2) * 4 + 64 * 4 + (size_t)KSTEPS * NPL * 2 * 64 * 16 +
                      (x_is_u8 ? 3 * 1024 * 4 : 0);
   const int items = n * (56 / SR);
-  if (x_is_u8) {
-    TT_TRY(ensure_dynamic_lds((const void *)stem_pc_kernel<true>, lds));
-    hipLaunchKernelGGL(stem_pc_kernel<true>, dim3(std::min(items, 256)), dim3(STEM_THREADS), lds, s, x, (const uint4 *)wfrag, init,
-                       rp, cp, p, n, norm_tab, range_flag);
-  } else {
-    TT_TRY(ensure_dynamic_lds((const void *)stem_pc_kernel<false>, lds));
-    hipLaunchKernelGGL(stem_pc_kernel<false>, dim3(std::min(items, 256)), dim3(STEM_THREADS), lds, s, x, (const uint4 *)wfrag,
-                       init, rp, cp, p, n, norm_tab, range_flag);
-  }
+  auto launch = [&](auto kernel) -> int {
+    TT_TRY(ensure_dynamic_lds((const void *)kernel, lds));
+    hipLaunchKernelGGL(kernel, dim3(std::min(items, 256)), dim3(STEM_THREADS), lds, s, x, (const uint4 *)wfrag, init, rp, cp, p, n,
+                       norm_tab, range_flag);
+    return TTNET_OK;
+  };
+  if (x_is_u8) TT_TRY(cp ? launch(stem_pc_kernel<true, true>) : launch(stem_pc_kernel<true, false>));
+  else TT_TRY(cp ? launch(stem_pc_kernel<false, true>) : launch(stem_pc_kernel<false, false>));
   TT_HIP(hipGetLastError());
   return TTNET_OK;
 }
