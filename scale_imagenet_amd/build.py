@@ -14,6 +14,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libttnet.so")
 SOURCES = ["plan.hip", "lut_build.hip", "stem.hip", "gate.hip", "gate_fused.hip", "gate_xs.hip", "gate_full.hip", "gate_va.hip", "head.hip", "preproc.hip"]
+# stem.hip: without -fno-slp-vectorize the producers' pooling adds become v_pk_add_f32 behind shuffling moves, which
+# beside the consumers' MFMAs cost 82 us per launch instead of 65 (tools/ubench/stem_parts.hip)
+EXTRA = {"stem.hip": ["-fno-slp-vectorize"]}
 FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function",
          "-ffp-contract=off"]
 
@@ -35,7 +38,7 @@ def build_lib(force: bool = False, verbose: bool = True) -> str:
         s = os.path.join(CSRC, src)
         o = os.path.join(objdir, src.replace(".hip", ".o"))
         if force or _stale(o, [s] + headers):
-            jobs.append([hipcc, *FLAGS, "-c", s, "-o", o])
+            jobs.append([hipcc, *FLAGS, *EXTRA.get(src, []), "-c", s, "-o", o])
 
     def run(cmd):
         if verbose:

@@ -970,7 +970,7 @@ int ttnet_plan_finalize(ttnet_plan *pl, void *stream) {
     return TTNET_OK;
   }
   // stem: BN scale folded into the weights, which are split into two prescaled fp16 planes in MFMA
-  // fragment order; BN shift as the accumulator start value
+  // fragment order; BN shift as the weights of one more k-row (stem.hip)
   {
     std::vector<float> w;
     TT_TRY(fetch(pl->tensors["features.1.weight"], w));
@@ -978,7 +978,10 @@ int ttnet_plan_finalize(ttnet_plan *pl, void *stream) {
     std::vector<double> sc, sh;
     TT_TRY(fold_bn(pl, "features.2", sc, sh));
     float init[64];
-    stem_split_weights(w.data(), sc.data(), sh.data(), pl->p, wf.data(), init);
+    if (!stem_split_weights(w.data(), sc.data(), sh.data(), pl->p, wf.data(), init)) {
+      set_error("stem: the folded BatchNorm shift of features.2 is outside the range of the split operands");
+      return TTNET_E_UNSUPPORTED;
+    }
     TT_HIP(hipMemcpy(pl->stem_wt, wf.data(), wf.size() * 2, hipMemcpyHostToDevice));
     TT_HIP(hipMemcpy(pl->stem_init, init, sizeof(init), hipMemcpyHostToDevice));
   }
@@ -1120,10 +1123,12 @@ bool capture_forward(ttnet_plan *pl, const void *x_dev, bool u8, int64_t n, floa
   if (hipGraphNodeGetType(e.first, &t0) != hipSuccess || hipGraphNodeGetType(e.last, &t1) != hipSuccess ||
       t0 != hipGraphNodeTypeKernel || t1 != hipGraphNodeTypeKernel || e.first == e.last)
     return false;
-  static const int first_sizes[9] = {8, 8, 8, 8, 8, 4, 4, 8, 8};  // stem_pc_kernel(x, wfrag, init, rp, cp, p, n, norm_tab, range_flag)
+  const int *first_sizes = nullptr;                               // stem_pc_kernel's arguments, from the file that declares it
+  const int first_n = stem_kernel_arg_sizes(&first_sizes);
   static const int first_sizes_va[7] = {8, 8, 8, 8, 8, 8, 4};     // va_stem_kernel(x, w, bias, scale, shift, rp, n)
   static const int last_sizes[8] = {8, 8, 8, 4, 8, 4, 4, 4};      // lin2_f16x2_kernel(A, B, bias, inv, out, M, N, KS)
-  e.first_nargs = pl->va ? 7 : 9;
+  e.first_nargs = pl->va ? 7 : first_n;
+  if (e.first_nargs > 12) return false;
   if (!own_params(e.first, pl->va ? first_sizes_va : first_sizes, e.first_nargs, e.first_p, e.first_argv, e.first_args) ||
       !own_params(e.last, last_sizes, kLastKernelArgs, e.last_p, e.last_argv, e.last_args))
     return false;

@@ -3,9 +3,7 @@
 // emitting the packed bits in both layouts the gate path reads (include/ttnet.h).
 //
 // Arithmetic.  Plain bf16 or fp16 operands flip ~0.07 % of the stem bits; the exact
-// f32 MFMA runs at 1/16 of the 16-bit MFMA rate, and on gfx950 VALU work does not hide under
-// another wave's MFMAs (tools/ubench/mfma_valu.hip: the two add up on a SIMD), so both the
-// matrix and the vector instruction counts matter.  Every f32 operand is split into two fp16
+// f32 MFMA runs at 1/16 of the 16-bit MFMA rate.  Every f32 operand is split into two fp16
 // terms, v = h1 + h2 + O(2^-22 |v|), after an exact power-of-two prescale that keeps the low
 // terms out of the fp16 subnormal range (x * 16, w * 2^k with max|w| 2^k in [8192, 16384); the
 // product of the two scales is divided out of the folded BatchNorm scale, exactly), and the
@@ -16,19 +14,34 @@
 // (|pre| < 1e-5) inside which the output bits are allowed to differ; the bits are
 // oracle-checked, exact except at near ties.  Input range: |x| < 4094 (fp16 overflow of 16 x); a
 // pooled value outside it raises the plan's range flag (ttnet.h: TTNET_E_RANGE), it never passes silently.
-// (Round-1 history: three bf16 terms / six products, 7e-8, cost twice the MFMAs and a third
-// LDS plane: 107 us at B = 256.)
 //
 // Shape.  Implicit GEMM  D[channel][pixel] = W[channel][k] * patch[k][pixel]  with
-// k = ((c*7 + kh)*8 + kw), kw padded 7 -> 8 with a zero weight so that one 8-element B-fragment
-// is 8 consecutive pooled pixels of one tile row.  v_mfma_f32_32x32x16_f16: M = 32 channels,
-// N = 32 output pixels, K = 16 = two (c,kh) rows.  One item = one image x 8 output rows
-// (448 pixels = 14 N-tiles); the pooled tile lives in LDS as two fp16 planes; the weights are
-// pre-split and pre-swizzled into fragment order at finalize and stream from L2 (45 KB,
-// shared by every workgroup).
+// k = ((c*7 + kh)*8 + slot), slot = kw + 1 (slot 0 carries a zero weight), so that the 8-element
+// B fragment of output pixel ox is the 8 consecutive pooled pixels 2ox-4 .. 2ox+3 of one tile row:
+// four whole dwords of a row that starts at pooled column -4.  v_mfma_f32_32x32x16_f16: M = 32
+// channels, N = 32 output pixels, K = 16 = two (c,kh) rows.  One item = one image x 8 output rows
+// (448 pixels = 14 N-tiles).
+//
+// Round 2 (the in-kernel stamps of tools/ubench/stem_parts.hip): a period of the round-1 kernel was
+// max(producers, consumers) with both near 14 k cycles -- the producers waiting for HBM (113 KB per
+// item), the consumers ADDING their parts (MFMA 7.4 k + fragment reads 2.8 k + loop overhead 2.5 k
+// + epilogue 1.7 k) because the two waves of a SIMD ran the same program in lockstep and eight
+// 4-byte LDS reads fed every three MFMAs.  This version:
+//  * the weight fragments of a wave's M-tile live in its registers for the whole kernel (88 VGPRs),
+//    not in LDS: no A-fragment reads, 44 KiB of LDS freed;
+//  * the freed LDS holds a second copy of every tile row, one dword to the left, so that the window
+//    of an odd pixel is 8-byte aligned too: a B fragment is four ds_read_b64, conflict-free (row
+//    pitch 60 dwords: the step to the next output row is 2*60 - 56 = 64 banks; the copies sit 32
+//    banks apart), instead of eight ds_read_b32;
+//  * a wave finishes one unit (N-tile x its M-tile) at a time, 33 MFMAs on one accumulator, its
+//    fragments read two k-steps ahead; the sign/pack epilogue of a unit then runs beside the other
+//    wave's MFMAs;
+//  * a producer lane pools two pixels from two 16-byte loads and writes packed dwords;
+//  * items are handed out so that the row blocks of an image run at the same time on one XCD: the
+//    5-row halo of a block comes from that L2 instead of HBM a second time (speed only).
 //
 // Bound: 16-bit MFMA (2.5 PFLOP/s dense) at 3 MFMA flops per algorithmic flop (3.6 with the
-// kw / row padding) plus the VALU work of the split and the epilogue; 29.5 MMAC/image.
+// slot / row padding) beside the HBM stream of the float32 input; 29.5 MMAC/image.
 
 #include <math.h>
 #include <string.h>
@@ -45,35 +58,51 @@ namespace {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
-constexpr int SR = 8;                  // output rows per workgroup
-constexpr int TR = 2 * SR + 5;         // pooled rows in the tile
-constexpr int TW = 120;                // tile row width in elements (118 used)
-constexpr int KSTEPS = 11;             // 22 (c,kh) rows (21 + one zero row), two per MFMA
-constexpr int NT = SR * 56 / 32;       // 14 N-tiles of 32 pixels
-constexpr int NPL = SPLIT_PLANES;      // fp16 planes per operand
-constexpr int ROWP = NPL * TW;         // LDS pitch of a tile row: [plane 0: TW][plane 1: TW], so that one
-                                       // address register reaches both planes of a fragment (ds_read2 offsets)
-constexpr int TILE = 3 * TR * ROWP;    // elements per tile buffer
+constexpr int SR = 8;                   // output rows per item
+constexpr int NBLK = 56 / SR;           // row blocks (items) per image
+constexpr int TR = 2 * SR + 5;          // pooled rows in the tile
+constexpr int ROWS = 3 * TR;            // (c, r) rows of a tile
+constexpr int PITCH = 60;               // dwords per tile row: 120 fp16 = pooled columns -4 .. 115
+constexpr int COPY_DW = ROWS * PITCH + 28;   // one copy of a plane; the +28 puts copy 1 thirty-two banks from copy 0
+constexpr int NPL = SPLIT_PLANES;       // fp16 planes per operand
+constexpr int PLANE_DW = 2 * COPY_DW;   // [copy 0: dword j = pixels (2j, 2j+1)][copy 1: dword j = copy 0's dword j+1]
+constexpr int TILE_DW = NPL * PLANE_DW; // dwords per tile buffer (60,928 B)
+constexpr int KSTEPS = 11;              // 22 (c,kh) rows (21 + one repeated with zero weights), two per MFMA
+constexpr int NT = SR * 56 / 32;        // 14 N-tiles of 32 pixels
 constexpr float X_PRESCALE = ACT_PRESCALE;
+
+// Diagnostic builds only (tools/ubench/stem_parts.hip): parts of the kernel switched off, in-kernel stamps.
+#ifndef TT_STEM_SKIP
+#define TT_STEM_SKIP 0
+#endif
+constexpr int kStemSkip = TT_STEM_SKIP;   // 1 no global loads, 2 no split, 4 no MFMA, 8 no fragment reads, 16 no epilogue, 32 no row words
+#ifdef TT_STEM_STAMP
+__device__ unsigned long long g_stem_stamps[256][2][16];
+#define STEM_STAMP(role, j) \
+  do { if (lane == 0 && (wave == 0 || wave == CONS_WAVES) && (j) < 16) g_stem_stamps[blockIdx.x][role][j] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define STEM_STAMP(role, j) do {} while (0)
+#endif
 
 constexpr int CONS_WAVES = 8, PROD_WAVES = 4, STEM_THREADS = 64 * (CONS_WAVES + PROD_WAVES);
 constexpr int UNITS = NT * 2;          // (N-tile, M-tile) pairs of one item: 28
-constexpr int UPW = (UNITS + CONS_WAVES - 1) / CONS_WAVES;   // units per consumer wave: 4 (waves 4-7: 3)
+constexpr int CONST_DW = ROWS * PITCH; // the constant block of the BatchNorm-shift row (16 bytes per plane, buffer 0)
+
+// tile row of (c,kh) row R = c*7 + kh (for the lane's output row 0)
+constexpr int tile_row(int R) { return (R / 7) * TR + R % 7; }
+
+struct __attribute__((packed, aligned(4))) U8x12 {
+  uint32_t a, b, c;
+};
 
 // Persistent producer / consumer kernel.  One workgroup per CU walks items (image, block of SR
-// output rows).  Producer waves stream the raw float32 rows from HBM, pool them and write the
-// two fp16 planes of the NEXT item's tile into the other half of an LDS double buffer;
+// output rows).  Producer waves stream the raw rows from HBM, pool them and write the two fp16
+// planes (two copies each) of the NEXT item's tile into the other half of an LDS double buffer;
 // consumer waves run the MFMAs and the sign/pack epilogue of the CURRENT item.  One workgroup
-// barrier per item.  Consumer wave w owns units w, w+8, ...: all of one M-tile (u & 1 = w & 1), so
-// a wave needs only that M-tile's weight fragments; waves w and w+4 share a SIMD and carry 4 + 3
-// units.  BatchNorm is folded: its scale into the weights (host), its shift into the initial
-// value of the accumulators, so the epilogue is the sign bit alone.
-//
-// Every vector instruction counts here (MFMA and VALU time add up on a SIMD): wave-uniform
-// indices are forced into SGPRs, border handling is a clamp of the load address plus a 0/4
-// multiplier instead of per-element selects, sign bits are collected by funnel shifts and turned
-// into row words by an in-register bit transpose (no ballots), and everything that does not
-// depend on the item is computed once.
+// barrier per item.  Consumer wave w owns units w, w+8, ...: all of one M-tile (u & 1 = w & 1);
+// waves w and w+4 share a SIMD and carry 4 + 3 units.  BatchNorm is folded: its scale into the
+// weights (host), its shift into the initial value of the accumulators, so the epilogue is the
+// sign bit alone.
 //
 // U8 = true: the input is the decoder's uint8 HWC image and the last two steps of
 // the input pipeline, ToTensor (/255) and Normalize(mean, std) (utils/preprocess.py:104-108),
@@ -89,131 +118,142 @@ template <bool U8, bool CP>
 __global__ __launch_bounds__(STEM_THREADS) void stem_pc_kernel(const void *__restrict__ xin, const uint4 *__restrict__ wfrag,
                                                                const float *__restrict__ init, uint64_t *__restrict__ rp,
                                                                uint16_t *__restrict__ cp, int p, int n_images,
-                                                               const uint32_t *__restrict__ norm_tab, uint32_t *range_flag) {
+                                                               const uint32_t *__restrict__ norm_tab, uint32_t *range_flag,
+                                                               int xcd_order) {
   const float *x = (const float *)xin;
   const uint8_t *xu8 = (const uint8_t *)xin;
   extern __shared__ __align__(16) uint8_t smem[];
-  uint16_t *tiles = (uint16_t *)smem;                               // [2][TILE] fp16
-  uint32_t(*stage)[64][NT + 2] = (uint32_t(*)[64][NT + 2])(smem + 2 * TILE * 2);   // [2][64][NT+2]
-  float *s_init = (float *)(smem + 2 * TILE * 2 + 2 * 64 * (NT + 2) * 4);          // [mtile][half][16] accumulator start values
-  uint4 *s_w = (uint4 *)(s_init + 64);                                             // weight fragments [ks][plane][mtile][lane]
-  uint32_t *s_norm = (uint32_t *)(s_w + KSTEPS * NPL * 2 * 64);                    // U8: [3][1024] h1 | h2 << 16
-  // The weight fragments (44 KiB) stay in LDS for the life of the workgroup: fetched from L2 every
-  // k-step they put an L2 round trip (under the producers' HBM traffic) on each of the 11 k-steps
-  // of every item -- the matrix pipe then idled for half of the MFMA phase.
-  for (int i = threadIdx.x; i < KSTEPS * NPL * 2 * 64; i += STEM_THREADS) s_w[i] = wfrag[i];
+  uint32_t *tiles = (uint32_t *)smem;                                              // [2][TILE_DW]
+  uint32_t(*stage)[64][NT + 2] = (uint32_t(*)[64][NT + 2])(smem + 2 * TILE_DW * 4);   // [2][64][NT+2]
+  uint32_t *s_norm = (uint32_t *)(smem + 2 * TILE_DW * 4 + 2 * 64 * (NT + 2) * 4);    // U8: [3][1024] h1 | h2 << 16
   if constexpr (U8)
     for (int i = threadIdx.x; i < 3 * 1024; i += STEM_THREADS) s_norm[i] = norm_tab[i];
   const int H = 224, W = 224;
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const bool producer = wave >= CONS_WAVES;
-  const int items = n_images * (56 / SR);
-  const int my_items = (items - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
-  if (threadIdx.x < 64) {
-    // C/D layout of the 32x32 MFMA: row (channel within the M-tile) = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
-    const int mm = threadIdx.x >> 5, hh = (threadIdx.x >> 4) & 1, r = threadIdx.x & 15;
-    s_init[threadIdx.x] = init[32 * mm + (r & 3) + 8 * (r >> 2) + 4 * hh];
+  // The folded BatchNorm shift enters the GEMM as one more k-row: the 22nd (c,kh) row reads a block of
+  // constants (slots 0 and 1 = c, a power of two; plane 1 = 0) instead of pixels, and its weights are
+  // shift / c split over the two slots (stem_split_weights), so the accumulators start from an inline
+  // zero and a unit needs no start values from LDS.  The block sits in the padding behind copy 0 of
+  // buffer 0, which no tile row reaches (only the very last padding dword is ever scribbled on).
+  if (threadIdx.x < 8) {
+    const uint32_t cb = (uint32_t)__builtin_bit_cast(uint16_t, (_Float16)init[0]);
+    tiles[(threadIdx.x >> 2) * PLANE_DW + CONST_DW + (threadIdx.x & 3)] = threadIdx.x == 0 ? (cb | (cb << 16)) : 0u;
   }
   if (threadIdx.x < 128) {
     stage[threadIdx.x >> 6][threadIdx.x & 63][NT] = 0;
     stage[threadIdx.x >> 6][threadIdx.x & 63][NT + 1] = 0;
   }
 
+  // ---- items ---------------------------------------------------------------------------------
+  // Plain order: item = block + j * grid.  XCD order (grid a multiple of 8; blocks b and b + 8 share an
+  // XCD under the observed round-robin placement): XCD b & 7 takes the images n = (b & 7) mod 8 and
+  // its blocks walk their row blocks in order, so neighbouring row blocks of an image are in flight
+  // together on one L2.
+  const int G = gridDim.x, bid = blockIdx.x;
+  const int slots = G >> 3, slot = bid >> 3, xcd = bid & 7;
+  int my_items;
+  if (xcd_order) {
+    const int imgs = xcd < n_images ? (n_images - xcd + 7) >> 3 : 0;
+    my_items = max(0, (NBLK * imgs - slot + slots - 1) / slots);
+  } else {
+    my_items = max(0, (n_images * NBLK - bid + G - 1) / G);
+  }
+  auto item_of = [&](int j, int &n, int &oy0) {
+    if (xcd_order) {
+      const int k = slot + j * slots;
+      n = xcd + 8 * (k / NBLK);
+      oy0 = (k % NBLK) * SR;
+    } else {
+      const int it = bid + j * G;
+      n = it / NBLK;
+      oy0 = (it % NBLK) * SR;
+    }
+  };
+
   // ---- producer side -----------------------------------------------------------------------
-  // tile column px = pooled image column px - 3; a lane handles px = lane and px = lane + 64
-  int colc[2];
-  float colm[2];
-#pragma unroll
-  for (int k = 0; k < 2; ++k) {
-    const int ix = lane + 64 * k - 3;
-    colc[k] = 2 * min(max(ix, 0), 111);
-    colm[k] = (ix >= 0 && ix < 112) ? 0.25f * X_PRESCALE : 0.0f;     // average of four, prescale; 0 in the padding
-  }
-  // U8: byte offset of the pooled pixel's two raw pixels (6 bytes: r g b r g b) in a raw row; mask
-  // of the padding columns
-  int colb[2];
-  uint32_t colk[2];
-#pragma unroll
-  for (int k = 0; k < 2; ++k) {
-    const int ix = lane + 64 * k - 3;
-    colb[k] = 6 * min(max(ix, 0), 111);
-    colk[k] = (ix >= 0 && ix < 112) ? 0xFFFFFFFFu : 0u;
-  }
-  constexpr int RPW8 = (TR + PROD_WAVES - 1) / PROD_WAVES;          // U8: pooled rows per producer wave (6), 3 channels each
-  typedef uint32_t __attribute__((aligned(2))) u32_a2;
-  uint32_t qa[RPW8][2][2], qb[RPW8][2][2];                          // [row][chunk][0: bytes 0-3, 1: bytes 4-5] of raw rows 2iy, 2iy+1
-  // pooled tile row r = pooled image row 2*oy0 - 3 + r; a producer wave owns the (c, r) rows pw,
-  // pw+4, ...  All global loads of an item are issued at once, one item ahead: they are in flight
-  // across the workgroup barrier and while the row words of the previous item are emitted, so
-  // the HBM latency is not on the per-item critical path (a producer that loads, waits and
-  // splits in turn needs 15.5 k cycles per item against 12 k for the consumers).
-  constexpr int RPW = (3 * TR + PROD_WAVES - 1) / PROD_WAVES;        // rows per producer wave: 16
-  float2 ra[RPW][2], rb[RPW][2];
+  // Tile column t = pooled image column t - 4.  Lane l < 60 makes dword l of a row = pooled pixels
+  // 2l-4 and 2l-3 = raw columns 4l-8 .. 4l-5: one 16-byte load per raw row (12 bytes of uint8).
+  // Border handling is a clamp of the load address plus a multiplier that is zero in the padding.
+  const int colraw = min(max(4 * lane - 8, 0), W - 4);
+  const bool col_ok = lane >= 2 && lane < 58;
+  const float colm = col_ok ? 0.25f * X_PRESCALE : 0.0f;      // average of four, prescale; 0 in the padding
+  // A producer wave owns the (c, r) rows pw, pw+4, ...  All global loads of an item are issued at
+  // once, one item ahead: they are in flight across the workgroup barrier and while the row words
+  // of the previous item are emitted, so the HBM latency is not on the per-item critical path.
+  constexpr int RPW = (ROWS + PROD_WAVES - 1) / PROD_WAVES;          // f32: (c, r) rows per producer wave: 16
+  constexpr int RPW8 = (TR + PROD_WAVES - 1) / PROD_WAVES;           // U8: pooled rows per producer wave (6), 3 channels each
+  float4 ra[U8 ? 1 : RPW], rb[U8 ? 1 : RPW];
+  U8x12 qa[U8 ? RPW8 : 1], qb[U8 ? RPW8 : 1];
   bool out_of_range = false;             // a pooled, prescaled value beyond fp16 (|x| >= 4094): see split_out_of_range
-  auto issue_loads = [&](int item) {
-    const int n = item / (56 / SR), oy0 = (item % (56 / SR)) * SR;
-    const int pw = wave - CONS_WAVES;                   // 0..3
+  const int pw = wave - CONS_WAVES;      // 0..3 (producers)
+  auto issue_loads = [&](int j) {
+    int n, oy0;
+    item_of(j, n, oy0);
     if constexpr (U8) {
 #pragma unroll
       for (int bi = 0; bi < RPW8; ++bi) {
         const int r = pw + PROD_WAVES * bi;             // wave-uniform
         const int iy = 2 * oy0 - 3 + r;
         const bool row_ok = r < TR && iy >= 0 && iy < 112;
-        const uint8_t *src_row = xu8 + ((size_t)n * H + 2 * (row_ok ? iy : 0)) * (W * 3);
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-          qa[bi][k][0] = *(const u32_a2 *)(src_row + colb[k]);
-          qa[bi][k][1] = *(const uint16_t *)(src_row + colb[k] + 4);
-          qb[bi][k][0] = *(const u32_a2 *)(src_row + W * 3 + colb[k]);
-          qb[bi][k][1] = *(const uint16_t *)(src_row + W * 3 + colb[k] + 4);
-        }
+        const uint8_t *src = xu8 + ((size_t)n * H + 2 * (row_ok ? iy : 0)) * (W * 3) + 3 * colraw;
+        qa[bi] = *(const U8x12 *)src;
+        qb[bi] = *(const U8x12 *)(src + W * 3);
       }
-      return;
-    }
+    } else {
 #pragma unroll
-    for (int bi = 0; bi < RPW; ++bi) {
-      const int cr = pw + PROD_WAVES * bi;              // wave-uniform
-      const int c = cr / TR, r = cr - c * TR;
-      const int iy = 2 * oy0 - 3 + r;
-      const bool row_ok = cr < 3 * TR && iy >= 0 && iy < 112;
-      const float *src_row = x + (((size_t)n * 3 + (row_ok ? c : 0)) * H + 2 * (row_ok ? iy : 0)) * W;
-#pragma unroll
-      for (int k = 0; k < 2; ++k) {
-        ra[bi][k] = *(const float2 *)(src_row + colc[k]);
-        rb[bi][k] = *(const float2 *)(src_row + W + colc[k]);
+      for (int bi = 0; bi < RPW; ++bi) {
+        const int cr = pw + PROD_WAVES * bi;              // wave-uniform
+        const int c = cr / TR, r = cr - c * TR;
+        const int iy = 2 * oy0 - 3 + r;
+        const bool row_ok = cr < ROWS && iy >= 0 && iy < 112;
+        const float *src = x + (((size_t)n * 3 + (row_ok ? c : 0)) * H + 2 * (row_ok ? iy : 0)) * W + colraw;
+        if constexpr (kStemSkip & 1) {
+          ra[bi] = make_float4((float)lane, 1.f, 2.f, (float)j);
+          rb[bi] = make_float4(2.f, (float)j, 1.f, (float)lane);
+        } else {
+          ra[bi] = *(const float4 *)src;
+          rb[bi] = *(const float4 *)(src + W);
+        }
       }
     }
   };
-  auto split_tile = [&](int item, uint16_t *tile) {
-    const int oy0 = (item % (56 / SR)) * SR;
-    const int pw = wave - CONS_WAVES;
+  auto split_tile = [&](int j, uint32_t *tile) {
+    if constexpr (kStemSkip & 2) return;
+    if (lane >= PITCH) return;             // one exec mask for the whole tile, not one per row
+    int n, oy0;
+    item_of(j, n, oy0);
     if constexpr (U8) {
+      const uint32_t colk = col_ok ? 0xFFFFFFFFu : 0u;
 #pragma unroll
       for (int bi = 0; bi < RPW8; ++bi) {
         const int r = pw + PROD_WAVES * bi;
         if (r < TR) {
           const int iy = 2 * oy0 - 3 + r;
-          const uint32_t rowk = (iy >= 0 && iy < 112) ? 0xFFFFFFFFu : 0u;     // wave-uniform
-          uint16_t *dst = tile + r * ROWP + lane;
+          const uint32_t keep = (iy >= 0 && iy < 112) ? colk : 0u;     // zero padding after the normalisation
+          const U8x12 a = qa[bi], b = qb[bi];
+          // bytes of a raw row: a.a = r0 g0 b0 r1, a.b = g1 b1 r2 g2, a.c = b2 r3 g3 b3 (pixels 0,1 -> first pooled pixel)
+          uint32_t s0[3], s1[3];
+          s0[0] = __builtin_amdgcn_udot4(a.a, 0x01000001u, __builtin_amdgcn_udot4(b.a, 0x01000001u, 0u, false), false);
+          s0[1] = __builtin_amdgcn_udot4(a.a, 0x00000100u, __builtin_amdgcn_udot4(b.a, 0x00000100u, 0u, false), false) +
+                  __builtin_amdgcn_udot4(a.b, 0x00000001u, __builtin_amdgcn_udot4(b.b, 0x00000001u, 0u, false), false);
+          s0[2] = __builtin_amdgcn_udot4(a.a, 0x00010000u, __builtin_amdgcn_udot4(b.a, 0x00010000u, 0u, false), false) +
+                  __builtin_amdgcn_udot4(a.b, 0x00000100u, __builtin_amdgcn_udot4(b.b, 0x00000100u, 0u, false), false);
+          s1[0] = __builtin_amdgcn_udot4(a.b, 0x00010000u, __builtin_amdgcn_udot4(b.b, 0x00010000u, 0u, false), false) +
+                  __builtin_amdgcn_udot4(a.c, 0x00000100u, __builtin_amdgcn_udot4(b.c, 0x00000100u, 0u, false), false);
+          s1[1] = __builtin_amdgcn_udot4(a.b, 0x01000000u, __builtin_amdgcn_udot4(b.b, 0x01000000u, 0u, false), false) +
+                  __builtin_amdgcn_udot4(a.c, 0x00010000u, __builtin_amdgcn_udot4(b.c, 0x00010000u, 0u, false), false);
+          s1[2] = __builtin_amdgcn_udot4(a.c, 0x01000001u, __builtin_amdgcn_udot4(b.c, 0x01000001u, 0u, false), false);
 #pragma unroll
-          for (int k = 0; k < 2; ++k) {
-            if (lane + 64 * k < TW) {
-              const uint32_t a0 = qa[bi][k][0], a1 = qa[bi][k][1], b0 = qb[bi][k][0], b1 = qb[bi][k][1];
-              // bytes: a0 = r0 g0 b0 r1, a1 = g1 b1 (likewise the second raw row)
-              uint32_t sum[3];
-              sum[0] = __builtin_amdgcn_udot4(a0, 0x01000001u, __builtin_amdgcn_udot4(b0, 0x01000001u, 0u, false), false);
-              sum[1] = __builtin_amdgcn_udot4(a0, 0x00000100u, __builtin_amdgcn_udot4(b0, 0x00000100u, a1 & 0xFFu, false), false) +
-                       (b1 & 0xFFu);
-              sum[2] = __builtin_amdgcn_udot4(a0, 0x00010000u, __builtin_amdgcn_udot4(b0, 0x00010000u, a1 >> 8, false), false) +
-                       (b1 >> 8);
-              const uint32_t keep = colk[k] & rowk;
-#pragma unroll
-              for (int c = 0; c < 3; ++c) {
-                const uint32_t hh = s_norm[c * 1024 + sum[c]] & keep;            // zero padding after the normalisation
-                dst[c * TR * ROWP + 64 * k] = (uint16_t)hh;
-                dst[c * TR * ROWP + 64 * k + TW] = (uint16_t)(hh >> 16);
-              }
-            }
+          for (int c = 0; c < 3; ++c) {
+            const uint32_t e0 = s_norm[c * 1024 + s0[c]] & keep, e1 = s_norm[c * 1024 + s1[c]] & keep;
+            const uint32_t d1 = __builtin_amdgcn_perm(e1, e0, 0x05040100u);      // h1 of both pixels
+            const uint32_t d2 = __builtin_amdgcn_perm(e1, e0, 0x07060302u);      // h2 of both pixels
+            uint32_t *dst = tile + (c * TR + r) * PITCH + lane;
+            dst[0] = d1;
+            dst[COPY_DW - 1] = d1;
+            dst[PLANE_DW] = d2;
+            dst[PLANE_DW + COPY_DW - 1] = d2;
           }
         }
       }
@@ -222,29 +262,31 @@ __global__ __launch_bounds__(STEM_THREADS) void stem_pc_kernel(const void *__res
 #pragma unroll
     for (int bi = 0; bi < RPW; ++bi) {
       const int cr = pw + PROD_WAVES * bi;
-      if (cr < 3 * TR) {
+      if (cr < ROWS) {
         const int c = cr / TR, r = cr - c * TR;
         const int iy = 2 * oy0 - 3 + r;
-        const float rowm = (iy >= 0 && iy < 112) ? 1.0f : 0.0f;      // wave-uniform
-        uint16_t *dst = tile + (c * TR + r) * ROWP + lane;
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-          if (lane + 64 * k < TW) {
-            // pooled value exactly as the reference forms it (x 0.25), times the exact prescale
-            const float v = (((ra[bi][k].x + ra[bi][k].y) + rb[bi][k].x) + rb[bi][k].y) * (colm[k] * rowm);
-            out_of_range |= split_out_of_range(v);
-            const _Float16 h1 = (_Float16)v;
-            const _Float16 h2 = (_Float16)(v - (float)h1);
-            dst[64 * k] = __builtin_bit_cast(uint16_t, h1);
-            dst[64 * k + TW] = __builtin_bit_cast(uint16_t, h2);
-          }
-        }
+        const float mul = (iy >= 0 && iy < 112) ? colm : 0.0f;
+        // pooled values exactly as the reference forms them (x 0.25), times the exact prescale
+        const float v0 = (((ra[bi].x + ra[bi].y) + rb[bi].x) + rb[bi].y) * mul;
+        const float v1 = (((ra[bi].z + ra[bi].w) + rb[bi].z) + rb[bi].w) * mul;
+        out_of_range |= split_out_of_range(v0) | split_out_of_range(v1);
+        const _Float16 g0 = (_Float16)v0, g1 = (_Float16)v1;
+        const _Float16 l0 = (_Float16)(v0 - (float)g0), l1 = (_Float16)(v1 - (float)g1);
+        const uint32_t d1 = (uint32_t)__builtin_bit_cast(uint16_t, g0) | ((uint32_t)__builtin_bit_cast(uint16_t, g1) << 16);
+        const uint32_t d2 = (uint32_t)__builtin_bit_cast(uint16_t, l0) | ((uint32_t)__builtin_bit_cast(uint16_t, l1) << 16);
+        uint32_t *dst = tile + cr * PITCH + lane;
+        dst[0] = d1;
+        dst[COPY_DW - 1] = d1;             // copy 1, one dword to the left (lane 0 lands in unused padding)
+        dst[PLANE_DW] = d2;
+        dst[PLANE_DW + COPY_DW - 1] = d2;
       }
     }
   };
-  // row words of a finished item from the ballots staged by the consumers
-  auto emit_rows = [&](int item, const uint32_t (*st)[NT + 2]) {
-    const int n = item / (56 / SR), oy0 = (item % (56 / SR)) * SR;
+  // row words of a finished item from the pieces staged by the consumers
+  auto emit_rows = [&](int j, const uint32_t (*st)[NT + 2]) {
+    if constexpr (kStemSkip & 32) return;
+    int n, oy0;
+    item_of(j, n, oy0);
     for (int idx = threadIdx.x - 64 * CONS_WAVES; idx < 64 * SR; idx += 64 * PROD_WAVES) {
       const int ch = idx & 63, row = idx >> 6;
       const int b0 = 56 * row, w0 = b0 >> 5, sft = b0 & 31;
@@ -260,99 +302,86 @@ __global__ __launch_bounds__(STEM_THREADS) void stem_pc_kernel(const void *__res
   const int h = lane >> 5, col = lane & 31;
   const DwLaneConst tk = dw_lane_const(lane);
   const int m = wave & 1;                                // this wave's M-tile (consumers only)
-  // per unit, independent of the item: dword offset of the lane's pixel in the tile, and its
-  // offset in a channel-word plane
-  int pixdw[UPW], cpoff[UPW];
-#pragma unroll
-  for (int i = 0; i < UPW; ++i) {
-    const int u = wave + CONS_WAVES * i, t = u >> 1;
-    const int pp = 32 * (u < UNITS ? t : 0) + col;
-    const int oyl = pp / 56, ox = pp - 56 * oyl;
-    pixdw[i] = (2 * oyl * ROWP + 2 * ox) >> 1;
-    cpoff[i] = oyl * 56 + ox;
-  }
-  auto compute_item = [&](int item, const uint16_t *tile, uint32_t (*st)[NT + 2], const f32x16 &start) {
-    const int n = item / (56 / SR), oy0 = (item % (56 / SR)) * SR;
-    f32x16 acc[UPW];
-#pragma unroll
-    for (int i = 0; i < UPW; ++i) acc[i] = start;
-    const uint32_t *tile32 = (const uint32_t *)tile;
-    // weights in fragment order [ks][plane][mtile][lane] x 16 bytes (LDS), read one k-step ahead
-    uint4 aw_next[NPL];
-#pragma unroll
-    for (int pl = 0; pl < NPL; ++pl) aw_next[pl] = s_w[(pl * 2 + m) * 64 + lane];
-#pragma unroll 1
-    for (int ks = 0; ks < KSTEPS; ++ks) {
-      uint4 aw[NPL];
-#pragma unroll
-      for (int pl = 0; pl < NPL; ++pl) aw[pl] = aw_next[pl];
-      if (ks + 1 < KSTEPS) {
-#pragma unroll
-        for (int pl = 0; pl < NPL; ++pl) aw_next[pl] = s_w[(((ks + 1) * NPL + pl) * 2 + m) * 64 + lane];
-      }
-      int R = 2 * ks + h;                    // (c,kh) row of this half-wave's 8 k values
-      if (R > 20) R = 20;                    // zero-weight pad row: any finite data
-      const int c = (R * 37) >> 8, kh = R - 7 * c;
-      const uint32_t *rowp = tile32 + (c * TR + kh) * (ROWP / 2);
-      const f16x8 w1 = __builtin_bit_cast(f16x8, aw[0]), w2 = __builtin_bit_cast(f16x8, aw[1]);
-      // the B fragments of unit i+1 are read from LDS while the three MFMAs of unit i run
-      // (two register sets; a wave that reads and multiplies in turn idles the matrix pipe for
-      // an LDS round trip per unit)
-      auto read_b = [&](int i, uint4 (&v)[NPL]) {
-        const uint32_t *q = rowp + pixdw[i];
-        v[0].x = q[0]; v[0].y = q[1]; v[0].z = q[2]; v[0].w = q[3];
-        v[1].x = q[TW / 2]; v[1].y = q[TW / 2 + 1]; v[1].z = q[TW / 2 + 2]; v[1].w = q[TW / 2 + 3];
-      };
-      uint4 bq[2][NPL];
-      read_b(0, bq[0]);
-#pragma unroll
-      for (int i = 0; i < UPW; ++i) {
-        if (i + 1 < UPW) read_b(i + 1, bq[(i + 1) & 1]);   // a 4th unit that does not exist repeats unit 0's address
-        __builtin_amdgcn_sched_barrier(0);                  // keep the reads ahead of the MFMAs
-        if (wave + CONS_WAVES * i < UNITS) {   // wave-uniform
-          const f16x8 x1 = __builtin_bit_cast(f16x8, bq[i & 1][0]), x2 = __builtin_bit_cast(f16x8, bq[i & 1][1]);
-          f32x16 a = acc[i];
-          a = __builtin_amdgcn_mfma_f32_32x32x16_f16(w2, x1, a, 0, 0, 0);
-          a = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1, x2, a, 0, 0, 0);
-          a = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1, x1, a, 0, 0, 0);
-          acc[i] = a;
-        }
-        __builtin_amdgcn_sched_barrier(0);
-      }
+  const int nunits = (UNITS - wave + CONS_WAVES - 1) / CONS_WAVES;     // 4 (waves 0-3) or 3
+  // byte offset, inside a tile buffer, of dword 0 of the lane's window in plane 0 and tile row 0:
+  // pixel pp of the item -> output row pp / 56, column ox; odd columns read copy 1
+  auto unit_addr = [&](int i) -> uint32_t {
+    const uint32_t t = (uint32_t)(wave >> 1) + 4u * (uint32_t)i;
+    const uint32_t pp = 32u * t + (uint32_t)col, oyl = pp / 56u, ox = pp - 56u * oyl, par = ox & 1u;
+    return 4u * (2u * oyl * PITCH + (ox - par) + par * COPY_DW);
+  };
+  // The two halves of a wave hold consecutive (c,kh) rows R = 2ks, 2ks+1: one tile row apart, except
+  // R = 6,7 (the next channel's first row: 15 tile rows on) and R = 20,21 (21 is the zero-weight pad: row 20 again).
+  const uint32_t hrow1 = (uint32_t)h * (PITCH * 4), hrow15 = (uint32_t)h * (15 * PITCH * 4);
+  // B fragments by inline assembly: left to the compiler, pairs of these reads (the two halves of a
+  // window, or two k-steps off one base) are fused into ds_read2_b64, which moves 128 B/clk where
+  // ds_read_b64 moves 256, and the reads drift next to their use.  The waits are counted by hand:
+  // LDS operations retire in order, so "all but the N youngest" is safe whatever else the compiler has
+  // in flight.  v: plane 0 low / high half, plane 1 low / high half of the lane's window.
+  auto read_frag = [&](uint32_t a1, uint32_t a15, uint32_t a0, auto ksc, unsigned long long (&v)[4]) {
+    constexpr int ks = decltype(ksc)::value;
+    if constexpr (kStemSkip & 8) {
+      v[0] = v[1] = v[2] = v[3] = (unsigned long long)a1 * (a15 + ks);
+      return;
     }
-    // epilogue: sign + pack.  C/D layout of the 32x32 MFMA: column = lane&31 (pixel),
-    // row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) (channel within the M-tile).  A lane collects the
-    // sign bits of its 16 registers (one funnel shift each: w = w<<1 | sign): that word is its
-    // pixel's share of the channel words; transposed across each 16-lane group it becomes, in lane
-    // j, register j's bits over the group's 16 pixels, i.e. the row-word pieces.  (A result of
-    // exactly -0.0 would count as negative here and as >= 0 in the reference: |pre| = 0 lies in
-    // the near-tie band either way.)
-#pragma unroll
-    for (int i = 0; i < UPW; ++i) {
-      const int u = wave + CONS_WAVES * i;
-      if (u >= UNITS) continue;
-      const int t = u >> 1;
-      uint32_t neg = 0;                      // bit r = sign bit of register r
-      static_for<0, 16>([&](auto rr) {
-        constexpr int r = 15 - decltype(rr)::value;
-        neg = __builtin_amdgcn_alignbit(neg, __float_as_uint(acc[i][r]), 31);
-      });
-      const uint32_t bits = ~neg & 0xFFFFu;  // bit r = (acc[r] >= 0)
-      if constexpr (CP) {
-        // channel word bit of register r: (r&3) + 8*((r>>2)&1) + 4*h within the 16-channel group r>>3
-        const uint32_t cw0 = bits & 0xFFu, cw1 = bits >> 8;
-        uint32_t pw = ((cw0 & 15u) | ((cw0 & 0xF0u) << 4)) | (((cw1 & 15u) | ((cw1 & 0xF0u) << 4)) << 16);
-        pw <<= 4 * h;
-        pw |= (uint32_t)__shfl_xor((int)pw, 32);
-        const int q = 2 * m + h;             // half-wave 0 stores group 2m, half-wave 1 group 2m+1
-        cp[((size_t)n * 4 + q) * (56 * 56) + oy0 * 56 + cpoff[i]] = (uint16_t)(h ? (pw >> 16) : pw);
-      }
-      // row-word pieces: lane j of a 16-lane group = register j over the group's 16 pixels
-      const uint32_t piece = transpose16(bits, tk) & 0xFFFFu;
-      const uint32_t other = (uint32_t)__shfl_xor((int)piece, 16);
-      if ((lane & 16) == 0) {                // lanes 0-15: channels of half 0, lanes 32-47: half 1 (+4)
-        const int j = lane & 15;
-        st[m * 32 + (j & 3) + 8 * (j >> 2) + 4 * h][t] = piece | (other << 16);
+    constexpr int off = tile_row(2 * ks) * (PITCH * 4);
+    const uint32_t a = (ks == 3 ? a15 : (ks == 10 ? a0 : a1)) + (uint32_t)(uintptr_t)smem;
+    asm volatile("ds_read_b64 %0, %4 offset:%5\n\tds_read_b64 %1, %4 offset:%6\n\t"
+                 "ds_read_b64 %2, %4 offset:%7\n\tds_read_b64 %3, %4 offset:%8"
+                 : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3])
+                 : "v"(a), "n"(off), "n"(off + 8), "n"(off + PLANE_DW * 4), "n"(off + PLANE_DW * 4 + 8));
+  };
+  auto frag = [](unsigned long long lo, unsigned long long hi) -> f16x8 {
+    const uint4 u = make_uint4((uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32));
+    return __builtin_bit_cast(f16x8, u);
+  };
+  // Epilogue of one unit: sign + pack.  C/D layout of the 32x32 MFMA: column = lane&31 (pixel),
+  // row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) (channel within the M-tile).  A lane collects the
+  // sign bits of its 16 registers (one funnel shift each: w = w<<1 | sign): that word is its
+  // pixel's share of the channel words; transposed across each 16-lane group it becomes, in lane
+  // j, register j's bits over the group's 16 pixels, i.e. the row-word pieces.  (A result of
+  // exactly -0.0 would count as negative here and as >= 0 in the reference: |pre| = 0 lies in
+  // the near-tie band either way.)  The sign collection runs at once (it frees the accumulator);
+  // the transpose -- DPP exchanges and one v_permlane16_swap, nothing that waits on the LDS queue --
+  // is cut into five pieces that ride in the issue gaps of the NEXT unit's MFMAs (epi_piece).
+  auto sign_bits = [&](const f32x16 &acc) -> uint32_t {
+    if constexpr (kStemSkip & 16) return __float_as_uint(acc[0]);
+    uint32_t neg = 0;                      // bit r = sign bit of register r
+    static_for<0, 16>([&](auto rr) {
+      constexpr int r = 15 - decltype(rr)::value;
+      neg = __builtin_amdgcn_alignbit(neg, __float_as_uint(acc[r]), 31);
+    });
+    return ~neg & 0xFFFFu;                 // bit r = (acc[r] >= 0)
+  };
+  auto channel_words = [&](uint32_t bits, int t, int n, int oy0) {
+    // channel word bit of register r: (r&3) + 8*((r>>2)&1) + 4*h within the 16-channel group r>>3
+    const uint32_t cw0 = bits & 0xFFu, cw1 = bits >> 8;
+    uint32_t pw2 = ((cw0 & 15u) | ((cw0 & 0xF0u) << 4)) | (((cw1 & 15u) | ((cw1 & 0xF0u) << 4)) << 16);
+    pw2 <<= 4 * h;
+    pw2 |= (uint32_t)__shfl_xor((int)pw2, 32);
+    const int q = 2 * m + h;             // half-wave 0 stores group 2m, half-wave 1 group 2m+1
+    const int pp = 32 * t + col, oyl = pp / 56, ox = pp - 56 * oyl;
+    cp[((size_t)n * 4 + q) * (56 * 56) + (oy0 + oyl) * 56 + ox] = (uint16_t)(h ? (pw2 >> 16) : pw2);
+  };
+  // piece 0..3: butterfly stage of the 16x16 bit transpose; piece 4: exchange between the two 16-lane
+  // rows of a half-wave and the store of the row-word piece (lanes 0-15: channels of half 0, lanes 32-47: half 1)
+  auto epi_piece = [&](auto pc, uint32_t &w, int t, uint32_t (*st)[NT + 2], bool live) {
+    constexpr int P = decltype(pc)::value;
+    if constexpr (kStemSkip & 16) {
+      if (P == 4 && live && w == 0x12345u) st[lane][t] = 1;
+      return;
+    }
+    if constexpr (P < 4) {
+      constexpr int S[4] = {8, 4, 2, 1};
+      const uint32_t partner = lane_xor16<S[P]>(w);
+      const uint32_t moved = __builtin_amdgcn_alignbit(partner, partner, tk.rot[P]);
+      w = moved ^ ((moved ^ w) & tk.keep[P]);
+    } else {
+      const uint32_t piece = w & 0xFFFFu;
+      const auto sw = __builtin_amdgcn_permlane16_swap(piece, piece, false, false);   // [1]: the value of lane ^ 16, in lanes 0-15 and 32-47
+      if (live && (lane & 16) == 0) {
+        const int jj = lane & 15;
+        st[m * 32 + (jj & 3) + 8 * (jj >> 2) + 4 * h][t] = piece | ((uint32_t)sw[1] << 16);
       }
     }
   };
@@ -361,30 +390,96 @@ __global__ __launch_bounds__(STEM_THREADS) void stem_pc_kernel(const void *__res
   // Period j: consumers work on item j (tile buffer j&1); producers emit the row words of item
   // j-1, split item j+1 (loaded during period j-1) into the other buffer and issue the loads of
   // item j+2.  Each role runs its own loop with the same my_items + 2 barriers.
-  const int g = gridDim.x, first = blockIdx.x;
   if (producer) {
-    if (my_items > 0) issue_loads(first);
+    STEM_STAMP(1, 0);
+    if (my_items > 0) issue_loads(0);
     __syncthreads();
-    if (my_items > 0) split_tile(first, tiles);
-    if (my_items > 1) issue_loads(first + g);
+    STEM_STAMP(1, 1);
+    if (my_items > 0) split_tile(0, tiles);
+    if (my_items > 1) issue_loads(1);
+    STEM_STAMP(1, 2);
     __syncthreads();
     for (int j = 0; j < my_items; ++j) {
-      const int item = first + j * g;
       // split first (its loads were issued most of a period ago), refill the load registers at
       // once, and only then the row words of the previous item: the loads get ~3/4 of a period
-      if (j + 1 < my_items) split_tile(item + g, tiles + ((j + 1) & 1) * TILE);
-      if (j + 2 < my_items) issue_loads(item + 2 * g);
-      if (j > 0) emit_rows(item - g, stage[(j - 1) & 1]);
+      if (j + 1 < my_items) split_tile(j + 1, tiles + ((j + 1) & 1) * TILE_DW);
+      if (j + 2 < my_items) issue_loads(j + 2);
+      if (j > 0) emit_rows(j - 1, stage[(j - 1) & 1]);
+      STEM_STAMP(1, 3 + j);
       __syncthreads();
     }
-    if (my_items > 0) emit_rows(first + (my_items - 1) * g, stage[(my_items - 1) & 1]);
+    if (my_items > 0) emit_rows(my_items - 1, stage[(my_items - 1) & 1]);
+    STEM_STAMP(1, 3 + my_items);
     if (out_of_range) *range_flag = 1u;
   } else {
+    // this wave's weight fragments, [ks][plane][mtile][lane] x 16 bytes in global memory (L2)
+    uint4 wreg[KSTEPS][NPL];
+#pragma unroll
+    for (int ks = 0; ks < KSTEPS; ++ks)
+#pragma unroll
+      for (int pl = 0; pl < NPL; ++pl) wreg[ks][pl] = wfrag[((ks * NPL + pl) * 2 + m) * 64 + lane];
+    STEM_STAMP(0, 0);
     __syncthreads();
     __syncthreads();
-    const f32x16 start = *(const f32x16 *)(s_init + (m * 2 + h) * 16);
+    STEM_STAMP(0, 2);
+    // address of the constant block for the half-wave that holds the shift row (k-step 10, h = 1),
+    // less that k-step's row offset, which read_frag adds as an immediate
+    const uint32_t a_shift = (uint32_t)(CONST_DW * 4 - tile_row(20) * (PITCH * 4));
     for (int j = 0; j < my_items; ++j) {
-      compute_item(first + j * g, tiles + (j & 1) * TILE, stage[j & 1], start);
+      int n, oy0;
+      item_of(j, n, oy0);
+      const uint32_t buf = (uint32_t)(j & 1) * (TILE_DW * 4);
+      uint32_t (*st)[NT + 2] = stage[j & 1];
+      // fragments are read two k-steps ahead, across unit boundaries
+      unsigned long long q0[4], q1[4];
+      {
+        const uint32_t a = unit_addr(0) + buf;
+        read_frag(a + hrow1, a + hrow15, a, std::integral_constant<int, 0>{}, q0);
+        read_frag(a + hrow1, a + hrow15, a, std::integral_constant<int, 1>{}, q1);
+      }
+      uint32_t pend = 0;                   // sign bits of the previous unit, its transpose in progress
+#pragma unroll 1
+      for (int i = 0; i < nunits; ++i) {
+        const uint32_t a = unit_addr(i) + buf, an = unit_addr(i + 1 < nunits ? i + 1 : i) + buf;
+        const uint32_t a1 = a + hrow1, a15 = a + hrow15, a10 = h ? a_shift : a, an1 = an + hrow1, an15 = an + hrow15;
+        const int tprev = (wave >> 1) + 4 * (i - 1);
+        unsigned long long f[KSTEPS + 2][4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          f[0][e] = q0[e];
+          f[1][e] = q1[e];
+        }
+        f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        static_for<0, KSTEPS>([&](auto ksc) {
+          constexpr int ks = decltype(ksc)::value;
+          if constexpr (ks + 2 < KSTEPS) read_frag(a1, a15, a10, std::integral_constant<int, ks + 2>{}, f[ks + 2]);
+          else read_frag(an1, an15, an, std::integral_constant<int, ks + 2 - KSTEPS>{}, f[ks + 2]);
+          // the fragments of k-steps ks+1 and ks+2 (8 reads) may still be in flight
+          if constexpr (!(kStemSkip & 8))
+            asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(f[ks][0]), "+v"(f[ks][1]), "+v"(f[ks][2]), "+v"(f[ks][3]));
+          const f16x8 w1 = __builtin_bit_cast(f16x8, wreg[ks][0]), w2 = __builtin_bit_cast(f16x8, wreg[ks][1]);
+          const f16x8 x1 = frag(f[ks][0], f[ks][1]), x2 = frag(f[ks][2], f[ks][3]);
+          if constexpr (kStemSkip & 4) {
+            acc[0] += (float)x1[0] + (float)x2[1] + (float)w1[2] + (float)w2[3];
+          } else {
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(w2, x1, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1, x2, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1, x1, acc, 0, 0, 0);
+          }
+          if constexpr (ks >= 1 && ks <= 5) epi_piece(std::integral_constant<int, ks - 1>{}, pend, tprev, st, i > 0);
+          __builtin_amdgcn_sched_barrier(0);     // reads stay two k-steps ahead of their MFMAs, no further
+        });
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          q0[e] = f[KSTEPS][e];
+          q1[e] = f[KSTEPS + 1][e];
+        }
+        pend = sign_bits(acc);
+        if constexpr (CP) channel_words(pend, (wave >> 1) + 4 * i, n, oy0);
+      }
+      // the last unit's transpose has no MFMAs to hide under
+      static_for<0, 5>([&](auto pc) { epi_piece(pc, pend, (wave >> 1) + 4 * (nunits - 1), st, true); });
+      STEM_STAMP(0, 3 + j);
       __syncthreads();
     }
   }
@@ -394,7 +489,7 @@ __global__ __launch_bounds__(STEM_THREADS) void stem_pc_kernel(const void *__res
 
 // Host side of the operand split: w [64][3][7][7] float32 -> fragment-ordered fp16 planes
 // [ks][plane][mtile][lane][8]: lane l of M-tile m holds channel 32m + (l&31), k = 16ks + 8(l>>5) + j,
-// k = ((c*7 + kh)*8 + kw); kw = 7 and the 22nd (c,kh) row carry zero weights.  init[64]: the
+// k = ((c*7 + kh)*8 + slot), slot = kw + 1; slot 0 carries a zero weight, the 22nd row the BatchNorm shift.  init[64]: the
 // accumulator start values (the folded BN shift in the prescaled unit).
 static uint16_t f32_to_f16_rne(float f) {
   uint32_t u;
@@ -416,26 +511,51 @@ static float f16_to_f32(uint16_t h) {
   return (h & 0x8000u) ? -mag : mag;
 }
 
-void stem_split_weights(const float *w, const double *scale, const double *shift, int p, uint16_t *out, float *init) {
+// init[0] = the constant c of the shift row (a power of two); returns false if the folded BatchNorm
+// shift is too large for it (|shift| x weight prescale x 16 >= 2^30).
+bool stem_split_weights(const float *w, const double *scale, const double *shift, int p, uint16_t *out, float *init) {
   // BatchNorm scale folded into the weights (float32 product, like any other float32 rounding of
-  // the reference's conv + BN chain), shift into the accumulator start value
+  // the reference's conv + BN chain); the shift becomes the weights of the 22nd (c,kh) row, whose
+  // "pixels" are the constant c in slots 0 and 1: slot 0 carries shift / c to 22 bits (two fp16
+  // terms), slot 1 what is left of it, so the sum is the float64 shift to well below one float32 ulp.
   std::vector<float> wf((size_t)p * 147);
   for (int ch = 0; ch < p; ++ch)
     for (int i = 0; i < 147; ++i) wf[(size_t)ch * 147 + i] = (float)((double)w[(size_t)ch * 147 + i] * scale[ch]);
   const float ws = weight_prescale(wf.data(), wf.size());
-  for (int ch = 0; ch < 64; ++ch) init[ch] = ch < p ? (float)(shift[ch] * (double)ws * (double)X_PRESCALE) : -1.0f;
+  double sh[64], amax = 0.0;
+  for (int ch = 0; ch < 64; ++ch) {
+    sh[ch] = ch < p ? shift[ch] * (double)ws * (double)X_PRESCALE : -1.0;      // channels beyond p: bit 0
+    amax = std::max(amax, std::fabs(sh[ch]));
+  }
+  if (!std::isfinite(amax)) return false;
+  double c = 1.0;
+  while (amax / c > 16384.0 && c < 32768.0) c *= 2.0;
+  if (amax / c > 32768.0) return false;
+  for (int i = 0; i < 64; ++i) init[i] = 0.f;
+  init[0] = (float)c;
   for (int ks = 0; ks < KSTEPS; ++ks)
     for (int m = 0; m < 2; ++m)
-      for (int l = 0; l < 64; ++l)
+      for (int l = 0; l < 64; ++l) {
+        const int ch = 32 * m + (l & 31), R = 2 * ks + (l >> 5);
+        double resid = 0.0;
         for (int j = 0; j < 8; ++j) {
-          const int ch = 32 * m + (l & 31), R = 2 * ks + (l >> 5), kw = j;
-          float v = 0.f;
-          if (ch < p && R < 21 && kw < 7) v = wf[(size_t)ch * 147 + R * 7 + kw] * ws;     // R = c*7 + kh
-          const uint16_t h1 = f32_to_f16_rne(v);
-          const uint16_t h2 = f32_to_f16_rne(v - f16_to_f32(h1));
+          const int kw = j - 1;
+          double v = 0.0;
+          if (R < 21) {
+            if (ch < p && kw >= 0) v = (double)(wf[(size_t)ch * 147 + R * 7 + kw] * ws);     // R = c*7 + kh
+          } else if (j == 0) {
+            v = sh[ch] / c;
+          } else if (j == 1) {
+            v = resid;
+          }
+          const uint16_t h1 = f32_to_f16_rne((float)v);
+          const uint16_t h2 = f32_to_f16_rne((float)(v - (double)f16_to_f32(h1)));
+          if (R == 21 && j == 0) resid = v - (double)f16_to_f32(h1) - (double)f16_to_f32(h2);
           const uint16_t parts[NPL] = {h1, h2};
           for (int pl = 0; pl < NPL; ++pl) out[((((size_t)ks * NPL + pl) * 2 + m) * 64 + l) * 8 + j] = parts[pl];
         }
+      }
+  return true;
 }
 
 size_t stem_split_weights_elems() { return (size_t)KSTEPS * NPL * 2 * 64 * 8; }
@@ -452,19 +572,33 @@ void stem_norm_table(const float mean[3], const float stdv[3], uint32_t *tab) {
     }
 }
 
+// (x, wfrag, init, rp, cp, p, n, norm_tab, range_flag, xcd_order): keep in step with the kernel's signature
+int stem_kernel_arg_sizes(const int **sizes) {
+  static const int kSizes[10] = {8, 8, 8, 8, 8, 4, 4, 8, 8, 4};
+  *sizes = kSizes;
+  return 10;
+}
+
+int g_stem_xcd_order = -1;      // diagnostic override (tools/ubench/stem_parts.hip): -1 = by batch size
+
 int launch_stem(const void *x, bool x_is_u8, const uint32_t *norm_tab, const void *wfrag, const float *init, uint64_t *rp,
                 uint16_t *cp, int n, int p, uint32_t *range_flag, hipStream_t s) {
   if (p < 1 || p > 64 || (cp && p != 64)) {
     set_error("stem: p=%d outside [1,64] (channel words need p = 64)", p);
     return TTNET_E_UNSUPPORTED;
   }
-  const size_t lds = (size_t)2 * TILE * 2 + (size_t)2 * 64 * (NT + 2) * 4 + 64 * 4 + (size_t)KSTEPS * NPL * 2 * 64 * 16 +
-                     (x_is_u8 ? 3 * 1024 * 4 : 0);
-  const int items = n * (56 / SR);
+  if (((uintptr_t)x & (x_is_u8 ? 3 : 15)) != 0) {
+    set_error("stem: the input must be %d-byte aligned", x_is_u8 ? 4 : 16);
+    return TTNET_E_INVALID;
+  }
+  const size_t lds = (size_t)2 * TILE_DW * 4 + (size_t)2 * 64 * (NT + 2) * 4 + (x_is_u8 ? 3 * 1024 * 4 : 0);
+  const int items = n * NBLK;
+  const int grid = std::min(items, 256);
+  const int xcd_order = g_stem_xcd_order >= 0 ? (g_stem_xcd_order && grid % 8 == 0) : ((grid == 256 && n >= 64) ? 1 : 0);
   auto launch = [&](auto kernel) -> int {
     TT_TRY(ensure_dynamic_lds((const void *)kernel, lds));
-    hipLaunchKernelGGL(kernel, dim3(std::min(items, 256)), dim3(STEM_THREADS), lds, s, x, (const uint4 *)wfrag, init, rp, cp, p, n,
-                       norm_tab, range_flag);
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(STEM_THREADS), lds, s, x, (const uint4 *)wfrag, init, rp, cp, p, n, norm_tab,
+                       range_flag, xcd_order);
     return TTNET_OK;
   };
   if (x_is_u8) TT_TRY(cp ? launch(stem_pc_kernel<true, true>) : launch(stem_pc_kernel<true, false>));
