@@ -63,7 +63,8 @@ constexpr int NBLK = 56 / SR;           // row blocks (items) per image
 constexpr int TR = 2 * SR + 5;          // pooled rows in the tile
 constexpr int ROWS = 3 * TR;            // (c, r) rows of a tile
 constexpr int PITCH = 60;               // dwords per tile row: 120 fp16 = pooled columns -4 .. 115
-constexpr int COPY_DW = ROWS * PITCH + 28;   // one copy of a plane; the +28 puts copy 1 thirty-two banks from copy 0
+constexpr int LROWS = 64;                // rows a copy holds: the tile's 63 and a spare one (a producer wave owns 16)
+constexpr int COPY_DW = LROWS * PITCH + 32;  // one copy of a plane; the +32 puts copy 1 thirty-two banks from copy 0
 constexpr int NPL = SPLIT_PLANES;       // fp16 planes per operand
 constexpr int PLANE_DW = 2 * COPY_DW;   // [copy 0: dword j = pixels (2j, 2j+1)][copy 1: dword j = copy 0's dword j+1]
 constexpr int TILE_DW = NPL * PLANE_DW; // dwords per tile buffer (60,928 B)
@@ -75,18 +76,36 @@ constexpr float X_PRESCALE = ACT_PRESCALE;
 #ifndef TT_STEM_SKIP
 #define TT_STEM_SKIP 0
 #endif
+#ifndef TT_STEM_PKCVT
+#define TT_STEM_PKCVT 0
+#endif
+#ifndef TT_STEM_PRIO
+#define TT_STEM_PRIO 2
+#endif
 constexpr int kStemSkip = TT_STEM_SKIP;   // 1 no global loads, 2 no split, 4 no MFMA, 8 no fragment reads, 16 no epilogue, 32 no row words
 #ifdef TT_STEM_STAMP
+#ifdef TT_STEM_REALTIME
+#define TT_STEM_CLOCK() (10ull * __builtin_amdgcn_s_memrealtime())      /* ns (100 MHz counter) */
+#else
+#define TT_STEM_CLOCK() __builtin_amdgcn_s_memtime()                    /* shader cycles */
+#endif
 __device__ unsigned long long g_stem_stamps[256][2][16];
 #define STEM_STAMP(role, j) \
-  do { if (lane == 0 && (wave == 0 || wave == CONS_WAVES) && (j) < 16) g_stem_stamps[blockIdx.x][role][j] = __builtin_amdgcn_s_memtime(); } while (0)
+  do { if (lane == 0 && (wave == 0 || wave == CONS_WAVES) && (j) < 16) g_stem_stamps[blockIdx.x][role][j] = TT_STEM_CLOCK(); } while (0)
 #else
 #define STEM_STAMP(role, j) do {} while (0)
 #endif
 
-constexpr int CONS_WAVES = 8, PROD_WAVES = 4, STEM_THREADS = 64 * (CONS_WAVES + PROD_WAVES);
+#ifndef TT_STEM_CONS
+#define TT_STEM_CONS 8
+#endif
+#ifndef TT_STEM_PROD
+#define TT_STEM_PROD 4
+#endif
+constexpr int CONS_WAVES = TT_STEM_CONS, PROD_WAVES = TT_STEM_PROD, STEM_THREADS = 64 * (CONS_WAVES + PROD_WAVES);
+static_assert(CONS_WAVES % 2 == 0, "a consumer wave keeps one M-tile: unit u = wave + CONS_WAVES * i has M-tile u & 1 = wave & 1");
 constexpr int UNITS = NT * 2;          // (N-tile, M-tile) pairs of one item: 28
-constexpr int CONST_DW = ROWS * PITCH; // the constant block of the BatchNorm-shift row (16 bytes per plane, buffer 0)
+constexpr int CONST_DW = LROWS * PITCH; // the constant block of the BatchNorm-shift row (16 bytes per plane, buffer 0)
 
 // tile row of (c,kh) row R = c*7 + kh (for the lane's output row 0)
 constexpr int tile_row(int R) { return (R / 7) * TR + R % 7; }
@@ -181,104 +200,122 @@ __global__ __launch_bounds__(STEM_THREADS) void stem_pc_kernel(const void *__res
   // A producer wave owns the (c, r) rows pw, pw+4, ...  All global loads of an item are issued at
   // once, one item ahead: they are in flight across the workgroup barrier and while the row words
   // of the previous item are emitted, so the HBM latency is not on the per-item critical path.
-  constexpr int RPW = (ROWS + PROD_WAVES - 1) / PROD_WAVES;          // f32: (c, r) rows per producer wave: 16
+  static_assert(U8 || PROD_WAVES * 16 == LROWS, "float32 input: a producer wave owns 16 consecutive tile rows");
   constexpr int RPW8 = (TR + PROD_WAVES - 1) / PROD_WAVES;           // U8: pooled rows per producer wave (6), 3 channels each
-  float4 ra[U8 ? 1 : RPW], rb[U8 ? 1 : RPW];
+  float4 ra[U8 ? 1 : 16], rb[U8 ? 1 : 16];
   U8x12 qa[U8 ? RPW8 : 1], qb[U8 ? RPW8 : 1];
   bool out_of_range = false;             // a pooled, prescaled value beyond fp16 (|x| >= 4094): see split_out_of_range
   const int pw = wave - CONS_WAVES;      // 0..3 (producers)
-  auto issue_loads = [&](int j) {
+  auto issue_loads = [&](int j) {             // uint8 input
     int n, oy0;
     item_of(j, n, oy0);
-    if constexpr (U8) {
 #pragma unroll
-      for (int bi = 0; bi < RPW8; ++bi) {
-        const int r = pw + PROD_WAVES * bi;             // wave-uniform
-        const int iy = 2 * oy0 - 3 + r;
-        const bool row_ok = r < TR && iy >= 0 && iy < 112;
-        const uint8_t *src = xu8 + ((size_t)n * H + 2 * (row_ok ? iy : 0)) * (W * 3) + 3 * colraw;
-        qa[bi] = *(const U8x12 *)src;
-        qb[bi] = *(const U8x12 *)(src + W * 3);
-      }
-    } else {
-#pragma unroll
-      for (int bi = 0; bi < RPW; ++bi) {
-        const int cr = pw + PROD_WAVES * bi;              // wave-uniform
-        const int c = cr / TR, r = cr - c * TR;
-        const int iy = 2 * oy0 - 3 + r;
-        const bool row_ok = cr < ROWS && iy >= 0 && iy < 112;
-        const float *src = x + (((size_t)n * 3 + (row_ok ? c : 0)) * H + 2 * (row_ok ? iy : 0)) * W + colraw;
-        if constexpr (kStemSkip & 1) {
-          ra[bi] = make_float4((float)lane, 1.f, 2.f, (float)j);
-          rb[bi] = make_float4(2.f, (float)j, 1.f, (float)lane);
-        } else {
-          ra[bi] = *(const float4 *)src;
-          rb[bi] = *(const float4 *)(src + W);
-        }
-      }
+    for (int bi = 0; bi < RPW8; ++bi) {
+      const int r = pw + PROD_WAVES * bi;             // wave-uniform
+      const int iy = 2 * oy0 - 3 + r;
+      const bool row_ok = r < TR && iy >= 0 && iy < 112;
+      const uint8_t *src = xu8 + ((size_t)n * H + 2 * (row_ok ? iy : 0)) * (W * 3) + 3 * colraw;
+      qa[bi] = *(const U8x12 *)src;
+      qb[bi] = *(const U8x12 *)(src + W * 3);
     }
   };
-  auto split_tile = [&](int j, uint32_t *tile) {
+  auto split_tile = [&](int j, uint32_t *tile) {   // uint8 input
     if constexpr (kStemSkip & 2) return;
     if (lane >= PITCH) return;             // one exec mask for the whole tile, not one per row
     int n, oy0;
     item_of(j, n, oy0);
-    if constexpr (U8) {
-      const uint32_t colk = col_ok ? 0xFFFFFFFFu : 0u;
+    const uint32_t colk = col_ok ? 0xFFFFFFFFu : 0u;
 #pragma unroll
-      for (int bi = 0; bi < RPW8; ++bi) {
-        const int r = pw + PROD_WAVES * bi;
-        if (r < TR) {
-          const int iy = 2 * oy0 - 3 + r;
-          const uint32_t keep = (iy >= 0 && iy < 112) ? colk : 0u;     // zero padding after the normalisation
-          const U8x12 a = qa[bi], b = qb[bi];
-          // bytes of a raw row: a.a = r0 g0 b0 r1, a.b = g1 b1 r2 g2, a.c = b2 r3 g3 b3 (pixels 0,1 -> first pooled pixel)
-          uint32_t s0[3], s1[3];
-          s0[0] = __builtin_amdgcn_udot4(a.a, 0x01000001u, __builtin_amdgcn_udot4(b.a, 0x01000001u, 0u, false), false);
-          s0[1] = __builtin_amdgcn_udot4(a.a, 0x00000100u, __builtin_amdgcn_udot4(b.a, 0x00000100u, 0u, false), false) +
-                  __builtin_amdgcn_udot4(a.b, 0x00000001u, __builtin_amdgcn_udot4(b.b, 0x00000001u, 0u, false), false);
-          s0[2] = __builtin_amdgcn_udot4(a.a, 0x00010000u, __builtin_amdgcn_udot4(b.a, 0x00010000u, 0u, false), false) +
-                  __builtin_amdgcn_udot4(a.b, 0x00000100u, __builtin_amdgcn_udot4(b.b, 0x00000100u, 0u, false), false);
-          s1[0] = __builtin_amdgcn_udot4(a.b, 0x00010000u, __builtin_amdgcn_udot4(b.b, 0x00010000u, 0u, false), false) +
-                  __builtin_amdgcn_udot4(a.c, 0x00000100u, __builtin_amdgcn_udot4(b.c, 0x00000100u, 0u, false), false);
-          s1[1] = __builtin_amdgcn_udot4(a.b, 0x01000000u, __builtin_amdgcn_udot4(b.b, 0x01000000u, 0u, false), false) +
-                  __builtin_amdgcn_udot4(a.c, 0x00010000u, __builtin_amdgcn_udot4(b.c, 0x00010000u, 0u, false), false);
-          s1[2] = __builtin_amdgcn_udot4(a.c, 0x01000001u, __builtin_amdgcn_udot4(b.c, 0x01000001u, 0u, false), false);
+    for (int bi = 0; bi < RPW8; ++bi) {
+      const int r = pw + PROD_WAVES * bi;
+      if (r < TR) {
+        const int iy = 2 * oy0 - 3 + r;
+        const uint32_t keep = (iy >= 0 && iy < 112) ? colk : 0u;     // zero padding after the normalisation
+        const U8x12 a = qa[bi], b = qb[bi];
+        // bytes of a raw row: a.a = r0 g0 b0 r1, a.b = g1 b1 r2 g2, a.c = b2 r3 g3 b3 (pixels 0,1 -> first pooled pixel)
+        uint32_t s0[3], s1[3];
+        s0[0] = __builtin_amdgcn_udot4(a.a, 0x01000001u, __builtin_amdgcn_udot4(b.a, 0x01000001u, 0u, false), false);
+        s0[1] = __builtin_amdgcn_udot4(a.a, 0x00000100u, __builtin_amdgcn_udot4(b.a, 0x00000100u, 0u, false), false) +
+                __builtin_amdgcn_udot4(a.b, 0x00000001u, __builtin_amdgcn_udot4(b.b, 0x00000001u, 0u, false), false);
+        s0[2] = __builtin_amdgcn_udot4(a.a, 0x00010000u, __builtin_amdgcn_udot4(b.a, 0x00010000u, 0u, false), false) +
+                __builtin_amdgcn_udot4(a.b, 0x00000100u, __builtin_amdgcn_udot4(b.b, 0x00000100u, 0u, false), false);
+        s1[0] = __builtin_amdgcn_udot4(a.b, 0x00010000u, __builtin_amdgcn_udot4(b.b, 0x00010000u, 0u, false), false) +
+                __builtin_amdgcn_udot4(a.c, 0x00000100u, __builtin_amdgcn_udot4(b.c, 0x00000100u, 0u, false), false);
+        s1[1] = __builtin_amdgcn_udot4(a.b, 0x01000000u, __builtin_amdgcn_udot4(b.b, 0x01000000u, 0u, false), false) +
+                __builtin_amdgcn_udot4(a.c, 0x00010000u, __builtin_amdgcn_udot4(b.c, 0x00010000u, 0u, false), false);
+        s1[2] = __builtin_amdgcn_udot4(a.c, 0x01000001u, __builtin_amdgcn_udot4(b.c, 0x01000001u, 0u, false), false);
 #pragma unroll
-          for (int c = 0; c < 3; ++c) {
-            const uint32_t e0 = s_norm[c * 1024 + s0[c]] & keep, e1 = s_norm[c * 1024 + s1[c]] & keep;
-            const uint32_t d1 = __builtin_amdgcn_perm(e1, e0, 0x05040100u);      // h1 of both pixels
-            const uint32_t d2 = __builtin_amdgcn_perm(e1, e0, 0x07060302u);      // h2 of both pixels
-            uint32_t *dst = tile + (c * TR + r) * PITCH + lane;
-            dst[0] = d1;
-            dst[COPY_DW - 1] = d1;
-            dst[PLANE_DW] = d2;
-            dst[PLANE_DW + COPY_DW - 1] = d2;
-          }
+        for (int c = 0; c < 3; ++c) {
+          const uint32_t e0 = s_norm[c * 1024 + s0[c]] & keep, e1 = s_norm[c * 1024 + s1[c]] & keep;
+          const uint32_t d1 = __builtin_amdgcn_perm(e1, e0, 0x05040100u);      // h1 of both pixels
+          const uint32_t d2 = __builtin_amdgcn_perm(e1, e0, 0x07060302u);      // h2 of both pixels
+          uint32_t *dst = tile + (c * TR + r) * PITCH + lane;
+          dst[0] = d1;
+          dst[COPY_DW - 1] = d1;             // copy 1, one dword to the left (lane 0 lands in unused padding)
+          dst[PLANE_DW] = d2;
+          dst[PLANE_DW + COPY_DW - 1] = d2;
         }
       }
-      return;
     }
+  };
+  // float32 input.  A producer wave owns 16 consecutive (c, r) rows of the tile (the 64th is a spare).
+  // One pass splits item js and, row by row, refills each row's registers with the same row of item
+  // jl as soon as it has been split: a load has a whole period to land and HBM always has loads of
+  // this wave in flight.  A single wave issues at most one instruction per four cycles, so the pass
+  // is written to be short: buffer loads (lane offset in a VGPR, row offset in an SGPR, the second
+  // raw row in the immediate) instead of 64-bit address arithmetic, out-of-range rows and columns
+  // left to the buffer's bounds check (they read as zero: the padding), the range check on the
+  // packed halves, one exec mask for the whole pass.  Everything inside is unconditional, so the
+  // waits stay counted (vmcnt(30): all but the 30 youngest); an absent item jl loads with an empty
+  // buffer (zeros, no traffic).
+  constexpr uint32_t IMG_BYTES = 3u * 224u * 224u * 4u;
+  const uint32_t lane_off = (lane >= 2 && lane < 58) ? (uint32_t)(4 * lane - 8) * 4u : 0x7FFF0000u;    // padding columns: out of range
+  uint32_t ovf = 0;                      // running packed max of |h1|: 0x7C00 and above in either half = fp16 overflow or NaN
+  auto f32_pass = [&](auto split_c, int js, int jl, uint32_t *tile) {
+    constexpr bool SPLIT = decltype(split_c)::value;
+    int ns = 0, oys = 0, nl = 0, oyl0 = 0;
+    if (SPLIT) item_of(js, ns, oys);
+    const bool load_ok = jl < my_items;
+    item_of(load_ok ? jl : 0, nl, oyl0);
+    const void *img = (const void *)(x + (size_t)nl * (3 * H * W));
+    if (lane < PITCH) {
 #pragma unroll
-    for (int bi = 0; bi < RPW; ++bi) {
-      const int cr = pw + PROD_WAVES * bi;
-      if (cr < ROWS) {
-        const int c = cr / TR, r = cr - c * TR;
-        const int iy = 2 * oy0 - 3 + r;
-        const float mul = (iy >= 0 && iy < 112) ? colm : 0.0f;
-        // pooled values exactly as the reference forms them (x 0.25), times the exact prescale
-        const float v0 = (((ra[bi].x + ra[bi].y) + rb[bi].x) + rb[bi].y) * mul;
-        const float v1 = (((ra[bi].z + ra[bi].w) + rb[bi].z) + rb[bi].w) * mul;
-        out_of_range |= split_out_of_range(v0) | split_out_of_range(v1);
-        const _Float16 g0 = (_Float16)v0, g1 = (_Float16)v1;
-        const _Float16 l0 = (_Float16)(v0 - (float)g0), l1 = (_Float16)(v1 - (float)g1);
-        const uint32_t d1 = (uint32_t)__builtin_bit_cast(uint16_t, g0) | ((uint32_t)__builtin_bit_cast(uint16_t, g1) << 16);
-        const uint32_t d2 = (uint32_t)__builtin_bit_cast(uint16_t, l0) | ((uint32_t)__builtin_bit_cast(uint16_t, l1) << 16);
-        uint32_t *dst = tile + cr * PITCH + lane;
-        dst[0] = d1;
-        dst[COPY_DW - 1] = d1;             // copy 1, one dword to the left (lane 0 lands in unused padding)
-        dst[PLANE_DW] = d2;
-        dst[PLANE_DW + COPY_DW - 1] = d2;
+      for (int bi = 0; bi < 16; ++bi) {
+        const int cr = 16 * pw + bi;                    // wave-uniform
+        const int c = (cr >= TR) + (cr >= 2 * TR) + (cr >= 3 * TR), r = cr - TR * c;
+        if constexpr (SPLIT && !(kStemSkip & 2)) {
+          // pooled values exactly as the reference forms them (x 0.25), times the exact prescale
+          const float v0 = (((ra[bi].x + ra[bi].y) + rb[bi].x) + rb[bi].y) * (0.25f * X_PRESCALE);
+          const float v1 = (((ra[bi].z + ra[bi].w) + rb[bi].z) + rb[bi].w) * (0.25f * X_PRESCALE);
+          const _Float16 g0 = (_Float16)v0, g1 = (_Float16)v1;
+          const _Float16 l0 = (_Float16)(v0 - (float)g0), l1 = (_Float16)(v1 - (float)g1);
+          const uint32_t d1 = (uint32_t)__builtin_bit_cast(uint16_t, g0) | ((uint32_t)__builtin_bit_cast(uint16_t, g1) << 16);
+          const uint32_t d2 = (uint32_t)__builtin_bit_cast(uint16_t, l0) | ((uint32_t)__builtin_bit_cast(uint16_t, l1) << 16);
+          typedef uint16_t u16x2 __attribute__((ext_vector_type(2)));
+          const u16x2 mag = __builtin_bit_cast(u16x2, d1 & 0x7FFF7FFFu), old = __builtin_bit_cast(u16x2, ovf);
+          ovf = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(mag, old));
+          uint32_t *dst = tile + cr * PITCH + lane;
+          dst[0] = d1;
+          dst[COPY_DW - 1] = d1;             // copy 1, one dword to the left (lane 0 lands in unused padding)
+          dst[PLANE_DW] = d2;
+          dst[PLANE_DW + COPY_DW - 1] = d2;
+        }
+        {
+          const int iy = 2 * oyl0 - 3 + r;
+          const bool row_ok = load_ok && c < 3 && iy >= 0 && iy < 112;
+          const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)img, 0, row_ok ? (int)IMG_BYTES : 0, 0x00020000);
+          const int soff = row_ok ? (c * H + 2 * iy) * W * 4 : 0;
+          if constexpr (kStemSkip & 1) {
+            ra[bi] = make_float4((float)lane, 1.f, 2.f, (float)jl);
+            rb[bi] = make_float4(2.f, (float)jl, 1.f, (float)lane);
+          } else {
+            typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+            const u32x4 a = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)lane_off, soff, 0);
+            const u32x4 b = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)lane_off + W * 4, soff, 0);
+            ra[bi] = __builtin_bit_cast(float4, a);
+            rb[bi] = __builtin_bit_cast(float4, b);
+          }
+        }
       }
     }
   };
@@ -306,7 +343,7 @@ __global__ __launch_bounds__(STEM_THREADS) void stem_pc_kernel(const void *__res
   // byte offset, inside a tile buffer, of dword 0 of the lane's window in plane 0 and tile row 0:
   // pixel pp of the item -> output row pp / 56, column ox; odd columns read copy 1
   auto unit_addr = [&](int i) -> uint32_t {
-    const uint32_t t = (uint32_t)(wave >> 1) + 4u * (uint32_t)i;
+    const uint32_t t = (uint32_t)(wave >> 1) + (uint32_t)(CONS_WAVES / 2) * (uint32_t)i;
     const uint32_t pp = 32u * t + (uint32_t)col, oyl = pp / 56u, ox = pp - 56u * oyl, par = ox & 1u;
     return 4u * (2u * oyl * PITCH + (ox - par) + par * COPY_DW);
   };
@@ -391,27 +428,41 @@ __global__ __launch_bounds__(STEM_THREADS) void stem_pc_kernel(const void *__res
   // j-1, split item j+1 (loaded during period j-1) into the other buffer and issue the loads of
   // item j+2.  Each role runs its own loop with the same my_items + 2 barriers.
   if (producer) {
+    if (TT_STEM_PRIO > 0) __builtin_amdgcn_s_setprio(TT_STEM_PRIO);
     STEM_STAMP(1, 0);
-    if (my_items > 0) issue_loads(0);
+    if constexpr (U8) {
+      if (my_items > 0) issue_loads(0);
+    } else {
+      if (my_items > 0) f32_pass(std::false_type{}, 0, 0, tiles);
+    }
     __syncthreads();
     STEM_STAMP(1, 1);
-    if (my_items > 0) split_tile(0, tiles);
-    if (my_items > 1) issue_loads(1);
+    if constexpr (U8) {
+      if (my_items > 0) split_tile(0, tiles);
+      if (my_items > 1) issue_loads(1);
+    } else {
+      if (my_items > 0) f32_pass(std::true_type{}, 0, 1, tiles);
+    }
     STEM_STAMP(1, 2);
     __syncthreads();
     for (int j = 0; j < my_items; ++j) {
-      // split first (its loads were issued most of a period ago), refill the load registers at
-      // once, and only then the row words of the previous item: the loads get ~3/4 of a period
-      if (j + 1 < my_items) split_tile(j + 1, tiles + ((j + 1) & 1) * TILE_DW);
-      if (j + 2 < my_items) issue_loads(j + 2);
+      if constexpr (U8) {
+        // split first (its loads were issued most of a period ago), refill the load registers at
+        // once, and only then the row words of the previous item
+        if (j + 1 < my_items) split_tile(j + 1, tiles + ((j + 1) & 1) * TILE_DW);
+        if (j + 2 < my_items) issue_loads(j + 2);
+      } else {
+        if (j + 1 < my_items) f32_pass(std::true_type{}, j + 1, j + 2, tiles + ((j + 1) & 1) * TILE_DW);
+      }
       if (j > 0) emit_rows(j - 1, stage[(j - 1) & 1]);
       STEM_STAMP(1, 3 + j);
       __syncthreads();
     }
     if (my_items > 0) emit_rows(my_items - 1, stage[(my_items - 1) & 1]);
     STEM_STAMP(1, 3 + my_items);
-    if (out_of_range) *range_flag = 1u;
+    if (out_of_range || (ovf & 0xFFFFu) >= 0x7C00u || (ovf >> 16) >= 0x7C00u) *range_flag = 1u;
   } else {
+    if (TT_STEM_PRIO < 0) __builtin_amdgcn_s_setprio(-TT_STEM_PRIO);
     // this wave's weight fragments, [ks][plane][mtile][lane] x 16 bytes in global memory (L2)
     uint4 wreg[KSTEPS][NPL];
 #pragma unroll
@@ -442,7 +493,7 @@ __global__ __launch_bounds__(STEM_THREADS) void stem_pc_kernel(const void *__res
       for (int i = 0; i < nunits; ++i) {
         const uint32_t a = unit_addr(i) + buf, an = unit_addr(i + 1 < nunits ? i + 1 : i) + buf;
         const uint32_t a1 = a + hrow1, a15 = a + hrow15, a10 = h ? a_shift : a, an1 = an + hrow1, an15 = an + hrow15;
-        const int tprev = (wave >> 1) + 4 * (i - 1);
+        const int tprev = (wave >> 1) + (CONS_WAVES / 2) * (i - 1);
         unsigned long long f[KSTEPS + 2][4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -475,10 +526,10 @@ __global__ __launch_bounds__(STEM_THREADS) void stem_pc_kernel(const void *__res
           q1[e] = f[KSTEPS + 1][e];
         }
         pend = sign_bits(acc);
-        if constexpr (CP) channel_words(pend, (wave >> 1) + 4 * i, n, oy0);
+        if constexpr (CP) channel_words(pend, (wave >> 1) + (CONS_WAVES / 2) * i, n, oy0);
       }
       // the last unit's transpose has no MFMAs to hide under
-      static_for<0, 5>([&](auto pc) { epi_piece(pc, pend, (wave >> 1) + 4 * (nunits - 1), st, true); });
+      static_for<0, 5>([&](auto pc) { epi_piece(pc, pend, (wave >> 1) + (CONS_WAVES / 2) * (nunits - 1), st, true); });
       STEM_STAMP(0, 3 + j);
       __syncthreads();
     }
