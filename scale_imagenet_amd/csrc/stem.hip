@@ -76,13 +76,16 @@ constexpr float X_PRESCALE = ACT_PRESCALE;
 #ifndef TT_STEM_SKIP
 #define TT_STEM_SKIP 0
 #endif
+#ifndef TT_STEM_LOAD_AUX
+#define TT_STEM_LOAD_AUX 0        /* cache policy of the input loads: 0 default, 2 nt */
+#endif
 #ifndef TT_STEM_PKCVT
 #define TT_STEM_PKCVT 0
 #endif
 #ifndef TT_STEM_PRIO
 #define TT_STEM_PRIO 2
 #endif
-constexpr int kStemSkip = TT_STEM_SKIP;   // 1 no global loads, 2 no split, 4 no MFMA, 8 no fragment reads, 16 no epilogue, 32 no row words
+constexpr int kStemSkip = TT_STEM_SKIP;   // 1 no global loads, 2 no split, 4 no MFMA, 8 no fragment reads, 16 no epilogue, 32 no row words, 64 no tile stores
 #ifdef TT_STEM_STAMP
 #ifdef TT_STEM_REALTIME
 #define TT_STEM_CLOCK() (10ull * __builtin_amdgcn_s_memrealtime())      /* ns (100 MHz counter) */
@@ -137,8 +140,7 @@ template <bool U8, bool CP>
 __global__ __launch_bounds__(STEM_THREADS) void stem_pc_kernel(const void *__restrict__ xin, const uint4 *__restrict__ wfrag,
                                                                const float *__restrict__ init, uint64_t *__restrict__ rp,
                                                                uint16_t *__restrict__ cp, int p, int n_images,
-                                                               const uint32_t *__restrict__ norm_tab, uint32_t *range_flag,
-                                                               int xcd_order) {
+                                                               const uint32_t *__restrict__ norm_tab, uint32_t *range_flag) {
   const float *x = (const float *)xin;
   const uint8_t *xu8 = (const uint8_t *)xin;
   extern __shared__ __align__(16) uint8_t smem[];
@@ -165,30 +167,21 @@ __global__ __launch_bounds__(STEM_THREADS) void stem_pc_kernel(const void *__res
   }
 
   // ---- items ---------------------------------------------------------------------------------
-  // Plain order: item = block + j * grid.  XCD order (grid a multiple of 8; blocks b and b + 8 share an
-  // XCD under the observed round-robin placement): XCD b & 7 takes the images n = (b & 7) mod 8 and
-  // its blocks walk their row blocks in order, so neighbouring row blocks of an image are in flight
-  // together on one L2.
+  // A workgroup takes a run of consecutive items in (image, row block) order, so most of its items
+  // continue the image of the one before: the five tile rows the two share are then copied from the
+  // previous tile inside LDS instead of being loaded, pooled and split again (16 of 21 rows to load:
+  // no byte of the input is read twice, and a quarter less producer work).
   const int G = gridDim.x, bid = blockIdx.x;
-  const int slots = G >> 3, slot = bid >> 3, xcd = bid & 7;
-  int my_items;
-  if (xcd_order) {
-    const int imgs = xcd < n_images ? (n_images - xcd + 7) >> 3 : 0;
-    my_items = max(0, (NBLK * imgs - slot + slots - 1) / slots);
-  } else {
-    my_items = max(0, (n_images * NBLK - bid + G - 1) / G);
-  }
+  const long long total_items = (long long)n_images * NBLK;
+  const int first_item = (int)(bid * total_items / G);
+  const int my_items = (int)((bid + 1) * total_items / G) - first_item;
   auto item_of = [&](int j, int &n, int &oy0) {
-    if (xcd_order) {
-      const int k = slot + j * slots;
-      n = xcd + 8 * (k / NBLK);
-      oy0 = (k % NBLK) * SR;
-    } else {
-      const int it = bid + j * G;
-      n = it / NBLK;
-      oy0 = (it % NBLK) * SR;
-    }
+    const int it = first_item + j;
+    n = it / NBLK;
+    oy0 = (it % NBLK) * SR;
   };
+  // item j continues the image of item j-1 of this workgroup
+  auto continues = [&](int j) -> bool { return j > 0 && (first_item + j) % NBLK != 0; };
 
   // ---- producer side -----------------------------------------------------------------------
   // Tile column t = pooled image column t - 4.  Lane l < 60 makes dword l of a row = pooled pixels
@@ -271,49 +264,90 @@ __global__ __launch_bounds__(STEM_THREADS) void stem_pc_kernel(const void *__res
   constexpr uint32_t IMG_BYTES = 3u * 224u * 224u * 4u;
   const uint32_t lane_off = (lane >= 2 && lane < 58) ? (uint32_t)(4 * lane - 8) * 4u : 0x7FFF0000u;    // padding columns: out of range
   uint32_t ovf = 0;                      // running packed max of |h1|: 0x7C00 and above in either half = fp16 overflow or NaN
+  // Rows of a pass: a whole tile is 63 rows, 16 consecutive ones per wave (slot bi -> tile row 16 pw + bi);
+  // an item that continues the previous one needs rows 5..20 of each channel, 12 per wave
+  // (slot bi < 12 -> channel (12 pw + bi) / 16, row 5 + (12 pw + bi) % 16), slots 12-15 unused.
+  auto slot_row = [&](bool cont, int bi, int &c, int &r) {
+    const int full = 16 * pw + bi, part = 12 * pw + bi;
+    const int cf = (full >= TR) + (full >= 2 * TR) + (full >= 3 * TR);
+    c = cont ? part >> 4 : cf;
+    r = cont ? 5 + (part & 15) : full - TR * cf;
+  };
   auto f32_pass = [&](auto split_c, int js, int jl, uint32_t *tile) {
     constexpr bool SPLIT = decltype(split_c)::value;
     int ns = 0, oys = 0, nl = 0, oyl0 = 0;
     if (SPLIT) item_of(js, ns, oys);
     const bool load_ok = jl < my_items;
     item_of(load_ok ? jl : 0, nl, oyl0);
+    const bool cont_s = SPLIT && continues(js), cont_l = load_ok && continues(jl);
     const void *img = (const void *)(x + (size_t)nl * (3 * H * W));
     if (lane < PITCH) {
-#pragma unroll
-      for (int bi = 0; bi < 16; ++bi) {
-        const int cr = 16 * pw + bi;                    // wave-uniform
-        const int c = (cr >= TR) + (cr >= 2 * TR) + (cr >= 3 * TR), r = cr - TR * c;
-        if constexpr (SPLIT && !(kStemSkip & 2)) {
-          // pooled values exactly as the reference forms them (x 0.25), times the exact prescale
-          const float v0 = (((ra[bi].x + ra[bi].y) + rb[bi].x) + rb[bi].y) * (0.25f * X_PRESCALE);
-          const float v1 = (((ra[bi].z + ra[bi].w) + rb[bi].z) + rb[bi].w) * (0.25f * X_PRESCALE);
-          const _Float16 g0 = (_Float16)v0, g1 = (_Float16)v1;
-          const _Float16 l0 = (_Float16)(v0 - (float)g0), l1 = (_Float16)(v1 - (float)g1);
-          const uint32_t d1 = (uint32_t)__builtin_bit_cast(uint16_t, g0) | ((uint32_t)__builtin_bit_cast(uint16_t, g1) << 16);
-          const uint32_t d2 = (uint32_t)__builtin_bit_cast(uint16_t, l0) | ((uint32_t)__builtin_bit_cast(uint16_t, l1) << 16);
-          typedef uint16_t u16x2 __attribute__((ext_vector_type(2)));
-          const u16x2 mag = __builtin_bit_cast(u16x2, d1 & 0x7FFF7FFFu), old = __builtin_bit_cast(u16x2, ovf);
-          ovf = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(mag, old));
-          uint32_t *dst = tile + cr * PITCH + lane;
-          dst[0] = d1;
-          dst[COPY_DW - 1] = d1;             // copy 1, one dword to the left (lane 0 lands in unused padding)
-          dst[PLANE_DW] = d2;
-          dst[PLANE_DW + COPY_DW - 1] = d2;
+      auto split_row = [&](auto bic) {
+        constexpr int bi = decltype(bic)::value;
+        int c, r;
+        slot_row(cont_s, bi, c, r);
+        // pooled values exactly as the reference forms them (x 0.25), times the exact prescale
+        const float v0 = (((ra[bi].x + ra[bi].y) + rb[bi].x) + rb[bi].y) * (0.25f * X_PRESCALE);
+        const float v1 = (((ra[bi].z + ra[bi].w) + rb[bi].z) + rb[bi].w) * (0.25f * X_PRESCALE);
+        const _Float16 g0 = (_Float16)v0, g1 = (_Float16)v1;
+        const _Float16 l0 = (_Float16)(v0 - (float)g0), l1 = (_Float16)(v1 - (float)g1);
+        const uint32_t d1 = (uint32_t)__builtin_bit_cast(uint16_t, g0) | ((uint32_t)__builtin_bit_cast(uint16_t, g1) << 16);
+        const uint32_t d2 = (uint32_t)__builtin_bit_cast(uint16_t, l0) | ((uint32_t)__builtin_bit_cast(uint16_t, l1) << 16);
+        typedef uint16_t u16x2 __attribute__((ext_vector_type(2)));
+        const u16x2 mag = __builtin_bit_cast(u16x2, d1 & 0x7FFF7FFFu), old = __builtin_bit_cast(u16x2, ovf);
+        ovf = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(mag, old));
+        uint32_t *dst = tile + (c * TR + r) * PITCH + lane;       // (the 64th row of a whole tile, c = 3, is the spare)
+        if constexpr (kStemSkip & 64) {
+          if (d1 == 0x12345678u && d2 == 0x9ABCDEF0u) dst[0] = d1;
+          return;
         }
-        {
-          const int iy = 2 * oyl0 - 3 + r;
-          const bool row_ok = load_ok && c < 3 && iy >= 0 && iy < 112;
-          const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)img, 0, row_ok ? (int)IMG_BYTES : 0, 0x00020000);
-          const int soff = row_ok ? (c * H + 2 * iy) * W * 4 : 0;
-          if constexpr (kStemSkip & 1) {
-            ra[bi] = make_float4((float)lane, 1.f, 2.f, (float)jl);
-            rb[bi] = make_float4(2.f, (float)jl, 1.f, (float)lane);
-          } else {
-            typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-            const u32x4 a = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)lane_off, soff, 0);
-            const u32x4 b = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)lane_off + W * 4, soff, 0);
-            ra[bi] = __builtin_bit_cast(float4, a);
-            rb[bi] = __builtin_bit_cast(float4, b);
+        dst[0] = d1;
+        dst[COPY_DW - 1] = d1;             // copy 1, one dword to the left (lane 0 lands in unused padding)
+        dst[PLANE_DW] = d2;
+        dst[PLANE_DW + COPY_DW - 1] = d2;
+      };
+      auto load_row = [&](auto bic) {
+        constexpr int bi = decltype(bic)::value;
+        int c, r;
+        slot_row(cont_l, bi, c, r);
+        const int iy = 2 * oyl0 - 3 + r;
+        const bool row_ok = load_ok && c < 3 && iy >= 0 && iy < 112;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)img, 0, row_ok ? (int)IMG_BYTES : 0, 0x00020000);
+        const int soff = row_ok ? (c * H + 2 * iy) * W * 4 : 0;
+        if constexpr (kStemSkip & 1) {
+          ra[bi] = make_float4((float)lane, 1.f, 2.f, (float)jl);
+          rb[bi] = make_float4(2.f, (float)jl, 1.f, (float)lane);
+        } else {
+          typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+          const u32x4 a = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)lane_off, soff, TT_STEM_LOAD_AUX);
+          const u32x4 b = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)lane_off + W * 4, soff, TT_STEM_LOAD_AUX);
+          ra[bi] = __builtin_bit_cast(float4, a);
+          rb[bi] = __builtin_bit_cast(float4, b);
+        }
+      };
+      static_for<0, 12>([&](auto bic) {
+        if constexpr (SPLIT && !(kStemSkip & 2)) split_row(bic);
+        load_row(bic);
+      });
+      // the four slots only a whole tile uses (the first item of a run or of an image)
+      if constexpr (SPLIT && !(kStemSkip & 2))
+        if (!cont_s) static_for<12, 16>([&](auto bic) { split_row(bic); });
+      if (!cont_l) static_for<12, 16>([&](auto bic) { load_row(bic); });
+    }
+    // rows 16..20 of the previous tile are rows 0..4 of this one: 3 channels x 5 rows x (2 planes x 2 copies),
+    // 240 bytes each, as 16-byte pieces, four row arrays per wave instruction
+    if (cont_s) {
+      const uint32_t *prev = tiles + ((js - 1) & 1) * TILE_DW;
+      const int piece = lane % 15, which = lane / 15;            // lanes 60-63 idle
+      if (which < 4) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int id = 16 * pw + 4 * k + which;                 // 0..63, 60 used: (array, channel, row)
+          if (id < 60) {
+            const int arr = id / 15, cr5 = id - 15 * arr, c = cr5 / 5, rr = cr5 - 5 * c;
+            const int base = (arr >> 1) * PLANE_DW + (arr & 1) * COPY_DW + (c * TR + rr) * PITCH + 4 * piece;
+            const uint4 v = *(const uint4 *)(prev + base + 16 * PITCH);
+            *(uint4 *)(tile + base) = v;
           }
         }
       }
@@ -623,14 +657,12 @@ void stem_norm_table(const float mean[3], const float stdv[3], uint32_t *tab) {
     }
 }
 
-// (x, wfrag, init, rp, cp, p, n, norm_tab, range_flag, xcd_order): keep in step with the kernel's signature
+// (x, wfrag, init, rp, cp, p, n, norm_tab, range_flag): keep in step with the kernel's signature
 int stem_kernel_arg_sizes(const int **sizes) {
-  static const int kSizes[10] = {8, 8, 8, 8, 8, 4, 4, 8, 8, 4};
+  static const int kSizes[9] = {8, 8, 8, 8, 8, 4, 4, 8, 8};
   *sizes = kSizes;
-  return 10;
+  return 9;
 }
-
-int g_stem_xcd_order = -1;      // diagnostic override (tools/ubench/stem_parts.hip): -1 = by batch size
 
 int launch_stem(const void *x, bool x_is_u8, const uint32_t *norm_tab, const void *wfrag, const float *init, uint64_t *rp,
                 uint16_t *cp, int n, int p, uint32_t *range_flag, hipStream_t s) {
@@ -645,11 +677,10 @@ int launch_stem(const void *x, bool x_is_u8, const uint32_t *norm_tab, const voi
   const size_t lds = (size_t)2 * TILE_DW * 4 + (size_t)2 * 64 * (NT + 2) * 4 + (x_is_u8 ? 3 * 1024 * 4 : 0);
   const int items = n * NBLK;
   const int grid = std::min(items, 256);
-  const int xcd_order = g_stem_xcd_order >= 0 ? (g_stem_xcd_order && grid % 8 == 0) : ((grid == 256 && n >= 64) ? 1 : 0);
   auto launch = [&](auto kernel) -> int {
     TT_TRY(ensure_dynamic_lds((const void *)kernel, lds));
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(STEM_THREADS), lds, s, x, (const uint4 *)wfrag, init, rp, cp, p, n, norm_tab,
-                       range_flag, xcd_order);
+                       range_flag);
     return TTNET_OK;
   };
   if (x_is_u8) TT_TRY(cp ? launch(stem_pc_kernel<true, true>) : launch(stem_pc_kernel<true, false>));

@@ -12,7 +12,6 @@
 #include "../../scale_imagenet_amd/csrc/stem.hip"
 
 namespace ttnet {
-extern int g_stem_xcd_order;
 void set_error(const char *fmt, ...) {
   va_list ap;
   va_start(ap, fmt);
@@ -34,7 +33,7 @@ int ensure_dynamic_lds(const void *kernel, size_t bytes) {
 
 int main(int argc, char **argv) {
   const int n = argc > 1 ? atoi(argv[1]) : 256;
-  if (argc > 2) ttnet::g_stem_xcd_order = atoi(argv[2]);
+
   const size_t xe = (size_t)n * 3 * 224 * 224;
   float *x;
   uint64_t *rp;
@@ -68,7 +67,7 @@ int main(int argc, char **argv) {
   hipEventSynchronize(e1);
   float ms = 0;
   hipEventElapsedTime(&ms, e0, e1);
-  printf("skip=%d n=%d xcd=%d: %.2f us per launch\n", TT_STEM_SKIP, n, ttnet::g_stem_xcd_order, 1e3 * ms / reps);
+  printf("skip=%d n=%d: %.2f us per launch\n", TT_STEM_SKIP, n, 1e3 * ms / reps);
 #ifdef TT_STEM_STAMP
   static unsigned long long st[256][2][16];
   hipMemcpyFromSymbol(st, HIP_SYMBOL(ttnet::g_stem_stamps), sizeof(st));
