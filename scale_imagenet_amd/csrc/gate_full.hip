@@ -237,12 +237,18 @@ __global__ __launch_bounds__(1024) void full_pw_kernel(FullPwArgs a) {
 // an exact tie could turn.
 typedef double f64x4 __attribute__((ext_vector_type(4)));
 
-template <int OT>      // 16-row output tiles: 2 (cout = 30) or 1 (cout = 15)
+// FIX: the tasks are not image rows but the pixels full_pw_fast_kernel listed (64 per wave, any images, any
+// positions); their bits are patched into the row words with atomics.
+template <int OT, bool FIX>      // 16-row output tiles: 2 (cout = 30) or 1 (cout = 15)
 __global__ __launch_bounds__(512) void full_pw_mfma_kernel(FullPwArgs a) {
   extern __shared__ __align__(16) double lds[];
   __shared__ double erf_tab[kErfN * kErfC];
   erf_table_to_lds(erf_tab);
   constexpr int CIN = 30, MT = 15, KS1 = 8;              // 240 hidden units, K = 30 padded to 32
+  if constexpr (FIX) {                                   // nothing listed for this workgroup: skip the weight staging too
+    const uint32_t capq = (uint32_t)a.n * (uint32_t)a.H * (uint32_t)a.W, cnt = min(a.fix_count[blockIdx.x], capq);
+    if (blockIdx.y * (blockDim.x >> 6) >= (cnt + 63u) / 64u) return;
+  }
   double *w1f = lds;                                     // [MT][KS1][64]
   double *w2f = w1f + MT * KS1 * 64;                     // [MT][4][OT][64]
   double *s1 = w2f + MT * 4 * OT * 64, *t1 = s1 + 16 * MT;
@@ -265,11 +271,29 @@ __global__ __launch_bounds__(512) void full_pw_mfma_kernel(FullPwArgs a) {
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nwaves = blockDim.x >> 6;
   const int lg = lane >> 4, ln = lane & 15;
   const int rpw = 64 / a.W, bundles = (a.H + rpw - 1) / rpw;
-  const int r = lane / a.W, x = lane - r * a.W;
-  const int tasks = a.n * bundles;
+  const uint32_t cap = (uint32_t)a.n * (uint32_t)a.H * (uint32_t)a.W;
+  const uint32_t listed = FIX ? min(a.fix_count[g], cap) : 0u;
+  const int tasks = FIX ? (int)((listed + 63u) / 64u) : a.n * bundles;
   for (int t = blockIdx.y * nwaves + wave; t < tasks; t += gridDim.y * nwaves) {
-    const int n = t / bundles, y0 = (t % bundles) * rpw, y = y0 + r;
-    const bool live = r < rpw && y < a.H;
+    int n, y0, y, x, r;
+    bool live;
+    uint32_t pid = 0;
+    if constexpr (FIX) {
+      live = (uint32_t)(64 * t + lane) < listed;
+      pid = live ? a.fix_list[(size_t)g * cap + 64 * t + lane] : 0u;
+      x = (int)(pid % (uint32_t)a.W);
+      y = (int)((pid / (uint32_t)a.W) % (uint32_t)a.H);
+      n = (int)(pid / (uint32_t)(a.W * a.H));
+      y0 = y;
+      r = 0;
+    } else {
+      r = lane / a.W;
+      x = lane - r * a.W;
+      n = t / bundles;
+      y0 = (t % bundles) * rpw;
+      y = y0 + r;
+      live = r < rpw && y < a.H;
+    }
     uint32_t in = 0;                                     // this lane's pixel: its 30 input bits
     if (live)
 #pragma unroll
@@ -324,7 +348,20 @@ __global__ __launch_bounds__(512) void full_pw_mfma_kernel(FullPwArgs a) {
         const int o = 16 * ot + 4 * i + lg;               // this lane's channel of the quartet
         const bool o_ok = o < cout;
         const double sc = o_ok ? a.s2[g * cout + o] : 0.0, sh = o_ok ? a.t2[g * cout + o] : -1.0;
-        if (a.out_float) {
+        if constexpr (FIX) {
+          // the value of (pixel tile nt, this lane) belongs to the pixel that lane 16 nt + l%16 was given
+#pragma unroll
+          for (int nt = 0; nt < 4; ++nt) {
+            const uint32_t pp = (uint32_t)__shfl((int)pid, 16 * nt + ln);
+            const bool there = (uint32_t)(64 * t + 16 * nt + ln) < listed;
+            const uint32_t px = pp % (uint32_t)a.W, py = (pp / (uint32_t)a.W) % (uint32_t)a.H, pn = pp / (uint32_t)(a.W * a.H);
+            if (o_ok && there) {
+              unsigned long long *word = (unsigned long long *)(a.out_rp + ((size_t)pn * a.Cout + g * cout + o) * a.H + py);
+              if (acc[ot][nt][i] * sc + sh >= 0.0) atomicOr(word, 1ull << px);
+              else atomicAnd(word, ~(1ull << px));
+            }
+          }
+        } else if (a.out_float) {
 #pragma unroll
           for (int nt = 0; nt < 4; ++nt) {
             const int p = 16 * nt + ln, pr = p / a.W, px = p - pr * a.W, py = y0 + pr;
@@ -345,6 +382,314 @@ __global__ __launch_bounds__(512) void full_pw_mfma_kernel(FullPwArgs a) {
         }
       }
   }
+}
+
+// ---- the same block on the 16-bit matrix cores, float64 only where the sign is in doubt --------------------------
+// 0.72 GFLOP per image in float64 is what bounds the variant (the kernel above: 61 k matrix-pipe cycles per
+// 64-pixel task).  The bit a block emits is sign(pre); it needs float64 only where |pre| is smaller than the
+// error of a cheaper evaluation.  So: evaluate every output in split-fp16 arithmetic on v_mfma_f32_16x16x32_f16
+// (the scheme of stem.hip: operands prescaled by a power of two and split into two fp16 terms, exact products,
+// float32 accumulation; the inputs of layer 1 are bits, exact in fp16, so it needs two products, layer 2 three)
+// with a float32 GELU, compare |pre| with a bound tau on that evaluation's error, and put the (pixel, group)
+// pairs that fail on a list; full_pw_mfma_kernel<OT, true> then re-evaluates the listed pixels in float64 and
+// patches their bits.  Every emitted bit is therefore the float64 bit -- the path is bit-identical to the
+// float64 one -- provided tau really bounds the error.  tau (per output channel, computed by the kernel from
+// the weights it stages): with A_m = sum_c |w1[m][c]|, zmax_m = |s1_m| A_m + |t1_m| (no hidden unit can exceed it),
+//     ez_m = |s1_m| A_m (2^-21 + 16 x 2^-24) + 3 x 2^-24 zmax_m       layer 1: operand split, accumulation, BatchNorm fma
+//     eg_m = 1.13 ez_m + 4e-7 (zmax_m + 0.1)                           GELU: its slope, its own error (below)
+//     E    = sum_m |w2[o][m]| eg_m + 3.1e-6 sum_m |w2[o][m]| zmax_m    layer 2: both operand splits, the dropped
+//                                                                      low x low product, 32 roundings of the sum
+//     tau  = 2 (|s2_o| E + 2^-22 |t2_o|)                               factor 2: margin
+// On the synthetic model about 1 in 1000 (pixel, group) pairs is listed.  The last block emits relu'd float32
+// features for a float32 head (tolerance 1e-5 on the logits): it takes the fast evaluation as it stands.
+//
+// gelu(z) = z Phi(z) with Phi from Abramowitz & Stegun 7.1.26 (|erf error| <= 1.5e-7), in the form
+// Phi(z) = h for z < 0, 1 - h otherwise, h = (1/2) poly(t) exp(-z^2/2), t = 1 / (1 + p |z| / sqrt 2): no
+// cancellation in the tail.  |gelu_f32(z) - gelu(z)| <= 4e-7 (|z| + 0.1) (tests/test_full_fast_bounds.py
+// checks the formula in float32 against float64 on a dense grid).
+__device__ inline float gelu_f32(float z) {
+  const float ax = __builtin_fabsf(z) * 0.70710678118654752440f;
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));
+  float p = fmaf(0.5f * 1.061405429f, t, 0.5f * -1.453152027f);
+  p = fmaf(p, t, 0.5f * 1.421413741f);
+  p = fmaf(p, t, 0.5f * -0.284496736f);
+  p = fmaf(p, t, 0.5f * 0.254829592f);
+  p = p * t;
+  const float h = p * __builtin_amdgcn_exp2f(-1.4426950408889634f * (ax * ax));
+  return z * (z < 0.f ? h : 1.0f - h);
+}
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+// Host and device: power of two that brings amax into [8192, 16384)
+__device__ inline float pow2_prescale(float amax) {
+  if (!(amax > 0.f) || !(amax < 3.0e38f)) return 1.0f;
+  int e;
+  (void)frexpf(amax, &e);
+  int k = 14 - e;
+  k = k > 60 ? 60 : (k < -60 ? -60 : k);
+  return ldexpf(1.0f, k);
+}
+__device__ inline void split_halves(float v, uint16_t &h1, uint16_t &h2) {
+  const _Float16 a = (_Float16)v, b = (_Float16)(v - (float)a);
+  h1 = __builtin_bit_cast(uint16_t, a);
+  h2 = __builtin_bit_cast(uint16_t, b);
+}
+
+constexpr int kFastMT = 15, kFastKP = 8, kFastMid = 240, kFastCin = 30;
+template <int OT>
+constexpr size_t fast_lds_bytes() {
+  return (size_t)kFastMT * 2 * 64 * 16 + (size_t)kFastKP * OT * 2 * 64 * 16 + 4 * 256 * sizeof(float) + 3 * 32 * sizeof(float) + 64;
+}
+
+template <int OT>      // 16-row output tiles: 2 (cout = 30) or 1 (cout = 15)
+__global__ __launch_bounds__(512) void full_pw_fast_kernel(FullPwArgs a) {
+  extern __shared__ __align__(16) uint8_t lds_raw[];
+  constexpr int CIN = kFastCin, MT = kFastMT, KP = kFastKP, MID = kFastMid;
+  uint4 *w1f = (uint4 *)lds_raw;                                // [MT][plane][lane]: layer-1 A fragments
+  uint4 *w2f = w1f + MT * 2 * 64;                               // [KP][OT][plane][lane]: layer-2 A fragments
+  float *s1f = (float *)(w2f + KP * OT * 2 * 64);               // [256] BatchNorm1 scale / layer-1 prescale
+  float *t1f = s1f + 256, *zmx = t1f + 256, *egm = zmx + 256;   // [256] each: shift; zmax_m; eg_m
+  float *s2f = egm + 256, *t2f = s2f + 32, *tau = t2f + 32;     // [32] each
+  float *red = tau + 32;                                        // [16] reductions
+  const int g = blockIdx.x, cout = a.cout;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nwaves = blockDim.x >> 6;
+  // ---- stage the group's weights: prescale, split, fragment order; the error bound ------------------
+  {
+    float m1 = 0.f, m2 = 0.f;
+    for (int i = threadIdx.x; i < MID * CIN; i += blockDim.x) m1 = fmaxf(m1, fabsf(a.w1[(size_t)g * MID * CIN + i]));
+    for (int i = threadIdx.x; i < cout * MID; i += blockDim.x) m2 = fmaxf(m2, fabsf(a.w2[(size_t)g * cout * MID + i]));
+    for (int o = 32; o > 0; o >>= 1) {
+      m1 = fmaxf(m1, __shfl_xor(m1, o));
+      m2 = fmaxf(m2, __shfl_xor(m2, o));
+    }
+    if (lane == 0) {
+      red[wave] = m1;
+      red[8 + wave] = m2;
+    }
+    __syncthreads();
+    m1 = 0.f;
+    m2 = 0.f;
+    for (int w = 0; w < nwaves; ++w) {
+      m1 = fmaxf(m1, red[w]);
+      m2 = fmaxf(m2, red[8 + w]);
+    }
+    const float ws1 = pow2_prescale(m1), ws2 = pow2_prescale(m2);
+    uint16_t *w1h = (uint16_t *)w1f, *w2h = (uint16_t *)w2f;
+    // layer 1, A[hidden 16 mt + l%16][input 8 (l/16) + j]
+    for (int i = threadIdx.x; i < MT * 64 * 8; i += blockDim.x) {
+      const int j = i & 7, l = (i >> 3) & 63, mt = i >> 9;
+      const int m = 16 * mt + (l & 15), k = 8 * (l >> 4) + j;
+      const float v = k < CIN ? a.w1[((size_t)g * MID + m) * CIN + k] * ws1 : 0.f;
+      uint16_t h1, h2;
+      split_halves(v, h1, h2);
+      w1h[((mt * 2 + 0) * 64 + l) * 8 + j] = h1;
+      w1h[((mt * 2 + 1) * 64 + l) * 8 + j] = h2;
+    }
+    // layer 2, A[output 16 ot + l%16][slot j of lane group q = l/16]: slots 0-3 = hidden 16 (2 kp) + 4 q + j,
+    // slots 4-7 = hidden 16 (2 kp + 1) + 4 q + (j - 4): exactly the registers a lane holds after layer 1
+    for (int i = threadIdx.x; i < KP * OT * 64 * 8; i += blockDim.x) {
+      const int j = i & 7, l = (i >> 3) & 63, ot = (i >> 9) % OT, kp = i / (512 * OT);
+      const int o = 16 * ot + (l & 15), q = l >> 4;
+      const int hid = 16 * (2 * kp + (j >> 2)) + 4 * q + (j & 3);
+      const float v = (o < cout && hid < MID) ? a.w2[((size_t)g * cout + o) * MID + hid] * ws2 : 0.f;
+      uint16_t h1, h2;
+      split_halves(v, h1, h2);
+      w2h[(((kp * OT + ot) * 2 + 0) * 64 + l) * 8 + j] = h1;
+      w2h[(((kp * OT + ot) * 2 + 1) * 64 + l) * 8 + j] = h2;
+    }
+    for (int m = threadIdx.x; m < 256; m += blockDim.x) {
+      if (m < MID) {
+        double A = 0.0;
+        for (int c = 0; c < CIN; ++c) A += fabs((double)a.w1[((size_t)g * MID + m) * CIN + c]);
+        const double sc = a.s1[g * MID + m], sh = a.t1[g * MID + m];
+        const double zmax = fabs(sc) * A + fabs(sh);
+        const double ez = fabs(sc) * A * (4.76837158203125e-7 + 16.0 * 5.9604644775390625e-8) + 3.0 * 5.9604644775390625e-8 * zmax;
+        s1f[m] = (float)(sc / (double)ws1);
+        t1f[m] = (float)sh;
+        zmx[m] = (float)zmax;
+        egm[m] = (float)(1.13 * ez + 4e-7 * (zmax + 0.1));
+      } else {
+        s1f[m] = 0.f; t1f[m] = 0.f; zmx[m] = 0.f; egm[m] = 0.f;
+      }
+    }
+    __syncthreads();
+    if (threadIdx.x < 32) {
+      const int o = threadIdx.x;
+      if (o < cout) {
+        double E = 0.0, S2 = 0.0;
+        for (int m = 0; m < MID; ++m) {
+          const double w = fabs((double)a.w2[((size_t)g * cout + o) * MID + m]);
+          E += w * (double)egm[m];
+          S2 += w * (double)zmx[m];
+        }
+        E += 3.1e-6 * S2;
+        const double sc = a.s2[g * cout + o], sh = a.t2[g * cout + o];
+        s2f[o] = (float)(sc / ((double)ws2 * (double)ACT_PRESCALE));
+        t2f[o] = (float)sh;
+        tau[o] = (float)(2.0 * (fabs(sc) * E + 2.384185791015625e-7 * fabs(sh)));
+      } else {
+        s2f[o] = 0.f; t2f[o] = -1.0f; tau[o] = 0.f;
+      }
+    }
+    __syncthreads();
+  }
+  const int lg = lane >> 4, ln = lane & 15;
+  const int rpw = 64 / a.W, bundles = (a.H + rpw - 1) / rpw;
+  const int r = lane / a.W, x = lane - r * a.W;
+  const int tasks = a.n * bundles;
+  const uint32_t cap = (uint32_t)a.n * (uint32_t)a.H * (uint32_t)a.W;
+  bool out_of_range = false;
+  for (int t = blockIdx.y * nwaves + wave; t < tasks; t += gridDim.y * nwaves) {
+    const int n = t / bundles, y0 = (t % bundles) * rpw, y = y0 + r;
+    const bool live = r < rpw && y < a.H;
+    uint32_t in = 0;                                     // this lane's pixel: its 30 input bits
+    if (live)
+#pragma unroll
+      for (int j = 0; j < CIN; ++j) {
+        const int J = CIN * g + j;
+        const uint64_t row = a.interleaved ? a.src[J & 3][((size_t)n * a.Csrc + (J >> 2)) * a.H + y]
+                                           : a.src[0][((size_t)n * a.Csrc + J) * a.H + y];
+        in |= (uint32_t)((row >> x) & 1ull) << j;
+      }
+    // layer-1 B fragments: lane l of pixel tile nt = input bits 8 (l/16) .. + 7 of pixel 16 nt + l%16, as fp16 0 / 1
+    uint4 xb[4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+      const uint32_t inp = ((uint32_t)__shfl((int)in, 16 * nt + ln) >> (8 * lg)) & 0xFFu;
+      uint32_t d[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) d[k] = ((inp >> (2 * k)) & 1u) * 0x3C00u + ((inp >> (2 * k + 1)) & 1u) * 0x3C000000u;
+      xb[nt] = make_uint4(d[0], d[1], d[2], d[3]);
+    }
+    f32x4 acc[OT][4];
+#pragma unroll
+    for (int ot = 0; ot < OT; ++ot)
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) acc[ot][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+    for (int kp = 0; kp < KP; ++kp) {
+      uint32_t g1[4][4], g2[4][4];                     // [pixel tile][dword]: high / low halves of 16 g, slots (0,1) (2,3) (4,5) (6,7)
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf) {
+        const int mt = 2 * kp + hf;
+        if (mt < MT) {
+          const f16x8 wa = __builtin_bit_cast(f16x8, w1f[(mt * 2 + 0) * 64 + lane]), wb = __builtin_bit_cast(f16x8, w1f[(mt * 2 + 1) * 64 + lane]);
+          const f32x4 sc = *(const f32x4 *)(s1f + 16 * mt + 4 * lg), sh = *(const f32x4 *)(t1f + 16 * mt + 4 * lg);
+#pragma unroll
+          for (int nt = 0; nt < 4; ++nt) {
+            const f16x8 xf = __builtin_bit_cast(f16x8, xb[nt]);
+            f32x4 d = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb, xf, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+            d = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa, xf, d, 0, 0, 0);
+            uint16_t hh[4], hl[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {               // register i = hidden unit 16 mt + 4 (l/16) + i
+              const float gv = gelu_f32(fmaf(d[i], sc[i], sh[i])) * ACT_PRESCALE;
+              out_of_range |= split_out_of_range(gv);
+              split_halves(gv, hh[i], hl[i]);
+            }
+            g1[nt][2 * hf] = (uint32_t)hh[0] | ((uint32_t)hh[1] << 16);
+            g1[nt][2 * hf + 1] = (uint32_t)hh[2] | ((uint32_t)hh[3] << 16);
+            g2[nt][2 * hf] = (uint32_t)hl[0] | ((uint32_t)hl[1] << 16);
+            g2[nt][2 * hf + 1] = (uint32_t)hl[2] | ((uint32_t)hl[3] << 16);
+          }
+        } else {
+#pragma unroll
+          for (int nt = 0; nt < 4; ++nt) g1[nt][2 * hf] = g1[nt][2 * hf + 1] = g2[nt][2 * hf] = g2[nt][2 * hf + 1] = 0u;
+        }
+      }
+#pragma unroll
+      for (int ot = 0; ot < OT; ++ot) {
+        const f16x8 wa = __builtin_bit_cast(f16x8, w2f[((kp * OT + ot) * 2 + 0) * 64 + lane]);
+        const f16x8 wb = __builtin_bit_cast(f16x8, w2f[((kp * OT + ot) * 2 + 1) * 64 + lane]);
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+          const f16x8 b1 = __builtin_bit_cast(f16x8, make_uint4(g1[nt][0], g1[nt][1], g1[nt][2], g1[nt][3]));
+          const f16x8 b2 = __builtin_bit_cast(f16x8, make_uint4(g2[nt][0], g2[nt][1], g2[nt][2], g2[nt][3]));
+          f32x4 c = acc[ot][nt];
+          c = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb, b1, c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa, b2, c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa, b1, c, 0, 0, 0);
+          acc[ot][nt] = c;
+        }
+      }
+    }
+    // acc[ot][nt][i] = output channel 16 ot + 4 (l/16) + i at pixel 16 nt + l%16
+    uint32_t doubt = 0;                                  // bit nt: some output of this lane at pixel tile nt is inside its bound
+#pragma unroll
+    for (int ot = 0; ot < OT; ++ot)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int o = 16 * ot + 4 * lg + i;              // this lane's channel of the quartet
+        const bool o_ok = o < cout;
+        const float sc = s2f[o], sh = t2f[o], tb = tau[o];
+        if (a.out_float) {
+#pragma unroll
+          for (int nt = 0; nt < 4; ++nt) {
+            const int p = 16 * nt + ln, pr = p / a.W, px = p - pr * a.W, py = y0 + pr;
+            const float pre = fmaf(acc[ot][nt][i], sc, sh);
+            if (o_ok && pr < rpw && py < a.H)
+              a.out_float[(((size_t)n * a.Cout + g * cout + o) * a.H + py) * a.W + px] = pre > 0.f ? pre : 0.f;
+          }
+        } else {
+          uint64_t bal[4];
+#pragma unroll
+          for (int nt = 0; nt < 4; ++nt) {
+            const float pre = fmaf(acc[ot][nt][i], sc, sh);
+            bal[nt] = __ballot(pre >= 0.f);
+            doubt |= (o_ok && !(__builtin_fabsf(pre) >= tb)) ? (1u << nt) : 0u;      // (a NaN is in doubt too)
+          }
+          // bits 16 q .. 16 q + 15 of a ballot = channel 16 ot + 4 q + i over the tile's 16 pixels; lane (q, row r' = l%16 < rpw)
+          // writes the row word of that channel, image row y0 + r'
+          const uint64_t mine = ((bal[0] >> (16 * lg)) & 0xFFFFull) | (((bal[1] >> (16 * lg)) & 0xFFFFull) << 16) |
+                                (((bal[2] >> (16 * lg)) & 0xFFFFull) << 32) | (((bal[3] >> (16 * lg)) & 0xFFFFull) << 48);
+          if (o_ok && ln < rpw && y0 + ln < a.H)
+            a.out_rp[((size_t)n * a.Cout + g * cout + o) * a.H + y0 + ln] = (mine >> (ln * a.W)) & ((1ull << a.W) - 1ull);
+        }
+      }
+    if (!a.out_float) {
+      // a pixel is listed if any of its channels (spread over the four lane groups) is in doubt
+      uint32_t mine = 0;                                 // lanes 0-15: bit nt = pixel 16 nt + lane is listed
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) {
+        const uint64_t b = __ballot((doubt >> nt) & 1u);
+        const uint32_t any = (uint32_t)((b | (b >> 16) | (b >> 32) | (b >> 48)) & 0xFFFFull);
+        mine |= ((any >> ln) & 1u) << nt;
+      }
+      if (lg != 0) mine = 0;
+      // drop the pixels beyond the bundle (idle lanes of the last rows)
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) {
+        const int p = 16 * nt + ln, pr = p / a.W;
+        if (!(pr < rpw && y0 + pr < a.H)) mine &= ~(1u << nt);
+      }
+      const int cnt = __popc(mine);
+      int total = cnt;                                   // wave-wide sum, this lane's offset in it
+      int before = 0;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const int v = __shfl_up(total, o);
+        if (lane >= o) total += v;
+      }
+      before = total - cnt;
+      const int wave_total = __shfl(total, 63);
+      if (wave_total) {
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(a.fix_count + g, (uint32_t)wave_total);
+        base = (uint32_t)__shfl((int)base, 0);
+        uint32_t k = base + (uint32_t)before;
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+          if ((mine >> nt) & 1u) {
+            const int p = 16 * nt + ln, pr = p / a.W, px = p - pr * a.W;
+            if (k < cap) a.fix_list[(size_t)g * cap + k] = ((uint32_t)n * (uint32_t)a.H + (uint32_t)(y0 + pr)) * (uint32_t)a.W + (uint32_t)px;
+            ++k;
+          }
+      }
+    }
+  }
+  if (out_of_range && a.range_flag) *a.range_flag = 1u;
 }
 
 // act(AvgPool2d(2)(x) - 0.5): floor-cropped 2x2 majority on row-packed planes, placed at (pad_t, pad_l)
@@ -393,18 +738,54 @@ int launch_full_dw(const FullDwArgs &a, hipStream_t s) {
   return TTNET_OK;
 }
 
+// TTNET_FULL_EXACT=1: every output in float64 (the round-1 path; what the fast path is tested against)
+static bool full_exact_only() {
+  static const bool v = [] {
+    const char *e = getenv("TTNET_FULL_EXACT");
+    return e && e[0] == '1';
+  }();
+  return v;
+}
+
 int launch_full_pw(const FullPwArgs &a, hipStream_t s) {
   if (a.cin == 30 && a.mid == 240 && (a.cout == 30 || a.cout == 15) && a.W <= 64) {
     const int ot = a.cout == 30 ? 2 : 1;
     const size_t lds = sizeof(double) * ((size_t)15 * 8 * 64 + (size_t)15 * 4 * ot * 64 + 2 * 240);
     const int rpw = 64 / a.W, tasks = a.n * ((a.H + rpw - 1) / rpw);
     const int chunks = std::max(1, std::min((tasks + 7) / 8, std::max(1, 512 / a.groups)));
+    const bool fast = !full_exact_only() && (a.out_float || (a.fix_list && a.fix_count)) && a.groups <= 64;
+    if (fast) {
+      if (!a.out_float) TT_HIP(hipMemsetAsync(a.fix_count, 0, 64 * sizeof(uint32_t), s));
+      // two workgroups per CU (64 KiB of fragments each)
+      const int fchunks = std::max(1, std::min((tasks + 7) / 8, std::max(1, 512 / a.groups)));
+      if (ot == 2) {
+        TT_TRY(ensure_dynamic_lds((const void *)full_pw_fast_kernel<2>, fast_lds_bytes<2>()));
+        hipLaunchKernelGGL(full_pw_fast_kernel<2>, dim3(a.groups, fchunks), dim3(512), fast_lds_bytes<2>(), s, a);
+      } else {
+        TT_TRY(ensure_dynamic_lds((const void *)full_pw_fast_kernel<1>, fast_lds_bytes<1>()));
+        hipLaunchKernelGGL(full_pw_fast_kernel<1>, dim3(a.groups, fchunks), dim3(512), fast_lds_bytes<1>(), s, a);
+      }
+      TT_HIP(hipGetLastError());
+      if (a.out_float) return TTNET_OK;
+      // the listed pixels in float64: a grid that could take 1/16 of all pixels at one task per wave; workgroups
+      // without listed pixels leave at once
+      const int xchunks = std::max(1, std::min((tasks / 16 + 7) / 8, std::max(1, 256 / a.groups)));
+      if (ot == 2) {
+        TT_TRY(ensure_dynamic_lds((const void *)full_pw_mfma_kernel<2, true>, lds));
+        hipLaunchKernelGGL((full_pw_mfma_kernel<2, true>), dim3(a.groups, xchunks), dim3(512), lds, s, a);
+      } else {
+        TT_TRY(ensure_dynamic_lds((const void *)full_pw_mfma_kernel<1, true>, lds));
+        hipLaunchKernelGGL((full_pw_mfma_kernel<1, true>), dim3(a.groups, xchunks), dim3(512), lds, s, a);
+      }
+      TT_HIP(hipGetLastError());
+      return TTNET_OK;
+    }
     if (ot == 2) {
-      TT_TRY(ensure_dynamic_lds((const void *)full_pw_mfma_kernel<2>, lds));
-      hipLaunchKernelGGL(full_pw_mfma_kernel<2>, dim3(a.groups, chunks), dim3(512), lds, s, a);
+      TT_TRY(ensure_dynamic_lds((const void *)full_pw_mfma_kernel<2, false>, lds));
+      hipLaunchKernelGGL((full_pw_mfma_kernel<2, false>), dim3(a.groups, chunks), dim3(512), lds, s, a);
     } else {
-      TT_TRY(ensure_dynamic_lds((const void *)full_pw_mfma_kernel<1>, lds));
-      hipLaunchKernelGGL(full_pw_mfma_kernel<1>, dim3(a.groups, chunks), dim3(512), lds, s, a);
+      TT_TRY(ensure_dynamic_lds((const void *)full_pw_mfma_kernel<1, false>, lds));
+      hipLaunchKernelGGL((full_pw_mfma_kernel<1, false>), dim3(a.groups, chunks), dim3(512), lds, s, a);
     }
     TT_HIP(hipGetLastError());
     return TTNET_OK;

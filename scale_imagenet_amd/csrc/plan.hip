@@ -114,6 +114,8 @@ struct ttnet_plan {
   uint64_t *va_y = nullptr;         // vAlexnet: the concatenated block output [n][256][11] rows
   float *va_scale = nullptr, *va_shift = nullptr;   // vAlexnet stem BatchNorm folded
   float *last_float = nullptr;      // full variant: relu'd output of the last block before AvgPool2d
+  uint32_t *full_fix = nullptr;     // full variant: [64] counters + the pixel lists of one grouped 1x1 block (gate_full.hip)
+  size_t full_fix_cap = 0;          // list entries
 
   // stem
   uint16_t *stem_wt = nullptr;      // fp16 x 2 split weights, fragment order
@@ -161,6 +163,7 @@ struct ttnet_plan {
     std::vector<uint32_t *> idx;
     uint64_t *va_y = nullptr;
     float *last_float = nullptr, *part = nullptr;
+    uint32_t *full_fix = nullptr;
     uint16_t *feat = nullptr, *mid_frag = nullptr;
     std::map<int64_t, GraphEntry> graphs;
     std::map<int64_t, int> eager_calls;
@@ -477,6 +480,13 @@ int alloc_workspace(ttnet_plan *pl) {
     if (pl->full) {
       const MultiHead &lb = pl->blocks.back();
       TT_TRY(dev_alloc(pl, &pl->last_float, (size_t)nb * lb.cf.g.out_planes * lb.Ho * lb.Wo, true, ws));
+      size_t cap = 0;                                  // pixels x groups of the largest binarised 1x1 block
+      for (const MultiHead &mh : pl->blocks) {
+        cap = std::max(cap, (size_t)mh.c3.g.groups * mh.H * mh.W);
+        if (!mh.last) cap = std::max(cap, (size_t)mh.cf.g.groups * mh.Ho * mh.Wo);
+      }
+      pl->full_fix_cap = cap * (size_t)nb;
+      TT_TRY(dev_alloc(pl, &pl->full_fix, 64 + pl->full_fix_cap, true, ws));
     }
   }
   const int nb_pad = (nb + 255) / 256 * 256;          // the lin1 GEMM walks whole 256-row tiles
@@ -503,6 +513,7 @@ void store_lane(ttnet_plan *pl, ttnet_plan::Lane &l) {
   }
   l.va_y = pl->va_y;
   l.last_float = pl->last_float;
+  l.full_fix = pl->full_fix;
   l.part = pl->part;
   l.feat = pl->feat;
   l.mid_frag = pl->mid_frag;
@@ -518,6 +529,7 @@ void load_lane(ttnet_plan *pl, const ttnet_plan::Lane &l) {
   }
   pl->va_y = l.va_y;
   pl->last_float = l.last_float;
+  pl->full_fix = l.full_fix;
   pl->part = l.part;
   pl->feat = l.feat;
   pl->mid_frag = l.mid_frag;
@@ -707,6 +719,7 @@ int run_full_block(ttnet_plan *pl, size_t i, int n, hipStream_t s) {
     a.w1 = wts(b, ".conv1.weight"); a.w2 = wts(b, ".conv2.weight");
     a.s1 = b.s1; a.t1 = b.t1; a.s2 = b.s2; a.t2 = b.t2;
     a.out_rp = mh.c3_tmp; a.out_float = nullptr;
+    a.fix_count = pl->full_fix; a.fix_list = pl->full_fix ? pl->full_fix + 64 : nullptr; a.range_flag = pl->range_dev;
     static const char *const kC3[4] = {"full.conv3.f4", "full.conv3.f5", "full.conv3.f6", "full.conv3.f7"};
     TT_TIMED(pl, kC3[std::min<size_t>(i, 3)], s, launch_full_pw(a, s));
     TT_TIMED(pl, "full.maj3", s,
@@ -723,6 +736,7 @@ int run_full_block(ttnet_plan *pl, size_t i, int n, hipStream_t s) {
     for (int k = 0; k < 4; ++k) a.src[k] = o64[k];
     a.w1 = wts(b, ".conv1.weight"); a.w2 = wts(b, ".conv2.weight");
     a.s1 = b.s1; a.t1 = b.t1; a.s2 = b.s2; a.t2 = b.t2;
+    a.fix_count = pl->full_fix; a.fix_list = pl->full_fix ? pl->full_fix + 64 : nullptr; a.range_flag = pl->range_dev;
     if (mh.last) {
       a.out_rp = nullptr; a.out_float = pl->last_float;
       TT_TIMED(pl, "full.convf_last", s, launch_full_pw(a, s));

@@ -291,6 +291,9 @@ struct FullPwArgs {
   const double *s1, *t1, *s2, *t2;
   uint64_t *out_rp;         // [n][Cout][H]  (binarised blocks)
   float *out_float;         // [n][Cout][H][W] relu'd (last block), or nullptr
+  // fast evaluation (gate_full.hip: full_pw_fast_kernel): the (pixel, group) pairs whose sign the split-fp16
+  // evaluation cannot vouch for, [groups][n*H*W] pixel ids and [64] counters; the range flag of the plan
+  uint32_t *fix_list, *fix_count, *range_flag;
 };
 int launch_full_dw(const FullDwArgs &a, hipStream_t s);
 int launch_full_pw(const FullPwArgs &a, hipStream_t s);
