@@ -14,9 +14,10 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libttnet.so")
 SOURCES = ["plan.hip", "lut_build.hip", "stem.hip", "gate.hip", "gate_fused.hip", "gate_xs.hip", "gate_full.hip", "gate_va.hip", "head.hip", "preproc.hip"]
+# gate_full.hip: the same flag keeps the float32 GELU of the fast kernels out of v_pk_* with shuffling moves.
 # stem.hip: without -fno-slp-vectorize the producers' pooling adds become v_pk_add_f32 behind shuffling moves, which
 # beside the consumers' MFMAs cost 82 us per launch instead of 65 (tools/ubench/stem_parts.hip)
-EXTRA = {"stem.hip": ["-fno-slp-vectorize"]}
+EXTRA = {"stem.hip": ["-fno-slp-vectorize"], "gate_full.hip": ["-fno-slp-vectorize"]}
 FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function",
          "-ffp-contract=off"]
 

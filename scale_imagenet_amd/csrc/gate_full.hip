@@ -403,20 +403,48 @@ __global__ __launch_bounds__(512) void full_pw_mfma_kernel(FullPwArgs a) {
 // On the synthetic model about 1 in 1000 (pixel, group) pairs is listed.  The last block emits relu'd float32
 // features for a float32 head (tolerance 1e-5 on the logits): it takes the fast evaluation as it stands.
 //
-// gelu(z) = z Phi(z) with Phi from Abramowitz & Stegun 7.1.26 (|erf error| <= 1.5e-7), in the form
-// Phi(z) = h for z < 0, 1 - h otherwise, h = (1/2) poly(t) exp(-z^2/2), t = 1 / (1 + p |z| / sqrt 2): no
-// cancellation in the tail.  |gelu_f32(z) - gelu(z)| <= 4e-7 (|z| + 0.1) (tests/test_full_fast_bounds.py
-// checks the formula in float32 against float64 on a dense grid).
-__device__ inline float gelu_f32(float z) {
-  const float ax = __builtin_fabsf(z) * 0.70710678118654752440f;
-  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));
-  float p = fmaf(0.5f * 1.061405429f, t, 0.5f * -1.453152027f);
-  p = fmaf(p, t, 0.5f * 1.421413741f);
-  p = fmaf(p, t, 0.5f * -0.284496736f);
-  p = fmaf(p, t, 0.5f * 0.254829592f);
-  p = p * t;
-  const float h = p * __builtin_amdgcn_exp2f(-1.4426950408889634f * (ax * ax));
-  return z * (z < 0.f ? h : 1.0f - h);
+// gelu(z) = z Phi(z) with Phi from a table in LDS: 512 nodes z_i = i / 32 on [-8, 8), at each the value, the
+// slope and half the curvature of Phi (float64 -> float32), evaluated as a quadratic around the nearest node:
+// |dz| <= 1/64, so the neglected cubic term is <= (1/64)^3 / 6 x max |third derivative of Phi| (0.4) = 2.5e-7,
+// and with the float32 roundings |gelu_f32(z) - gelu(z)| <= 4e-7 (|z| + 0.1) (tests/test_full_fast_bounds.py
+// checks the formula in float32 against float64 on a dense grid).  Nine vector instructions and one 16-byte LDS
+// read; the Abramowitz-Stegun form it replaced (a reciprocal, an exponential, five fmas) cost twice that and set
+// the kernel's time.  Beyond the table Phi is 0 or 1 to 1e-15: the edge nodes hold exactly that, with no slope.
+constexpr int kPhiN = 512;
+// (slope and curvature are stored for an offset measured in the caller's units: z x scale)
+__device__ inline void phi_table_to_lds(float4 *dst, const double *erf_tab, double scale) {
+  for (int i = threadIdx.x; i < kPhiN; i += blockDim.x) {
+    const double z = (double)(i - kPhiN / 2) * (1.0 / 32.0);
+    const double x = z * 0.70710678118654752440, ax = __builtin_fabs(x);
+    int k = (int)(ax * 8.0);
+    k = k < kErfN - 1 ? k : kErfN - 1;
+    const double t = ax - ((double)k + 0.5) * 0.125;
+    const double *c = erf_tab + k * kErfC;
+    double p = c[8];
+    for (int q = 7; q >= 0; --q) p = fma(p, t, c[q]);
+    p = ax >= 6.0 ? 1.0 : p;
+    const double Phi = 0.5 * (1.0 + __builtin_copysign(p, x));
+    const double pdf = 0.39894228040143267794 * exp(-0.5 * z * z);
+    const bool edge = i == 0 || i == kPhiN - 1;
+    dst[i] = edge ? make_float4(i ? 1.f : 0.f, 0.f, 0.f, 0.f)
+                  : make_float4((float)Phi, (float)(pdf / scale), (float)(-0.5 * z * pdf / (scale * scale)), 0.f);
+  }
+}
+// z x SCALE in, gelu(z) x SCALE out (SCALE = ACT_PRESCALE: the prescale of layer 2's operand rides along for free).
+// In two steps so that a batch of table reads can be in flight before the first is needed.
+template <int SCALE>
+__device__ inline int gelu_node(float zs, float &dz) {
+  float r = __builtin_rintf(zs * (32.0f / (float)SCALE));               // nearest node, in units of 1/32
+  r = __builtin_fminf(__builtin_fmaxf(r, -(float)(kPhiN / 2)), (float)(kPhiN / 2 - 1));
+  dz = fmaf(r, -(float)SCALE / 32.0f, zs);                             // offset from the node, in units of 1 / SCALE
+  return (int)r + kPhiN / 2;
+}
+__device__ inline float gelu_eval(float zs, float dz, const float4 &c) { return zs * fmaf(dz, fmaf(dz, c.z, c.y), c.x); }
+template <int SCALE>
+__device__ inline float gelu_f32(float zs, const float4 *tab) {
+  float dz;
+  const int i = gelu_node<SCALE>(zs, dz);
+  return gelu_eval(zs, dz, tab[i]);
 }
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -438,13 +466,29 @@ __device__ inline void split_halves(float v, uint16_t &h1, uint16_t &h2) {
 }
 
 constexpr int kFastMT = 15, kFastKP = 8, kFastMid = 240, kFastCin = 30;
+// tools/ubench/full_pw_parts.hip builds this file with parts of full_pw_fast_kernel switched off (bit mask:
+// 1 no tasks (staging only), 2 no input gather, 4 no layer 1 / GELU, 8 no layer 2, 16 no epilogue).  0 in the library.
+#ifndef TT_FULLPW_SKIP
+#define TT_FULLPW_SKIP 0
+#endif
+constexpr int kPwSkip = TT_FULLPW_SKIP;
+#ifdef TT_FULLPW_STAMP
+__device__ unsigned long long g_pw_stamps[8];        // ns spent by wave 0 of block (0,0): gather, layer 1 + GELU, layer 2, epilogue, tasks
+#define PW_STAMP(k) do { if (stamping) { const unsigned long long now = 10ull * __builtin_amdgcn_s_memrealtime(); g_pw_stamps[k] += now - stamp_t; stamp_t = now; } } while (0)
+#else
+#define PW_STAMP(k) do {} while (0)
+#endif
 template <int OT>
 constexpr size_t fast_lds_bytes() {
-  return (size_t)kFastMT * 2 * 64 * 16 + (size_t)kFastKP * OT * 2 * 64 * 16 + 4 * 256 * sizeof(float) + 3 * 32 * sizeof(float) + 64;
+  return (size_t)kFastMT * 2 * 64 * 16 + (size_t)kFastKP * OT * 2 * 64 * 16 + 4 * 256 * sizeof(float) + 3 * 32 * sizeof(float) + 64 +
+         (size_t)kPhiN * 16;
 }
 
 template <int OT>      // 16-row output tiles: 2 (cout = 30) or 1 (cout = 15)
-__global__ __launch_bounds__(512) void full_pw_fast_kernel(FullPwArgs a) {
+#ifndef TT_FULLPW_MINWAVES
+#define TT_FULLPW_MINWAVES 2      /* one workgroup per CU; 4 = two, at most 128 registers: spills, and no faster */
+#endif
+__global__ __launch_bounds__(512, TT_FULLPW_MINWAVES) void full_pw_fast_kernel(FullPwArgs a) {
   extern __shared__ __align__(16) uint8_t lds_raw[];
   constexpr int CIN = kFastCin, MT = kFastMT, KP = kFastKP, MID = kFastMid;
   uint4 *w1f = (uint4 *)lds_raw;                                // [MT][plane][lane]: layer-1 A fragments
@@ -453,6 +497,9 @@ __global__ __launch_bounds__(512) void full_pw_fast_kernel(FullPwArgs a) {
   float *t1f = s1f + 256, *zmx = t1f + 256, *egm = zmx + 256;   // [256] each: shift; zmax_m; eg_m
   float *s2f = egm + 256, *t2f = s2f + 32, *tau = t2f + 32;     // [32] each
   float *red = tau + 32;                                        // [16] reductions
+  float4 *phi = (float4 *)(red + 16);                           // [512] GELU table
+  __shared__ double erf_tab[kErfN * kErfC];
+  erf_table_to_lds(erf_tab);
   const int g = blockIdx.x, cout = a.cout;
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nwaves = blockDim.x >> 6;
   // ---- stage the group's weights: prescale, split, fragment order; the error bound ------------------
@@ -468,7 +515,9 @@ __global__ __launch_bounds__(512) void full_pw_fast_kernel(FullPwArgs a) {
       red[wave] = m1;
       red[8 + wave] = m2;
     }
+    if (threadIdx.x == 0) red[15] = 0.f;
     __syncthreads();
+    phi_table_to_lds(phi, erf_tab, (double)ACT_PRESCALE);
     m1 = 0.f;
     m2 = 0.f;
     for (int w = 0; w < nwaves; ++w) {
@@ -506,10 +555,11 @@ __global__ __launch_bounds__(512) void full_pw_fast_kernel(FullPwArgs a) {
         const double sc = a.s1[g * MID + m], sh = a.t1[g * MID + m];
         const double zmax = fabs(sc) * A + fabs(sh);
         const double ez = fabs(sc) * A * (4.76837158203125e-7 + 16.0 * 5.9604644775390625e-8) + 3.0 * 5.9604644775390625e-8 * zmax;
-        s1f[m] = (float)(sc / (double)ws1);
-        t1f[m] = (float)sh;
+        s1f[m] = (float)(sc * (double)ACT_PRESCALE / (double)ws1);
+        t1f[m] = (float)(sh * (double)ACT_PRESCALE);
         zmx[m] = (float)zmax;
         egm[m] = (float)(1.13 * ez + 4e-7 * (zmax + 0.1));
+        if (!(zmax * (double)ACT_PRESCALE < 65000.0)) red[15] = 1.0f;     // |gelu(z)| <= |z| <= zmax: only then can a split overflow
       } else {
         s1f[m] = 0.f; t1f[m] = 0.f; zmx[m] = 0.f; egm[m] = 0.f;
       }
@@ -541,18 +591,37 @@ __global__ __launch_bounds__(512) void full_pw_fast_kernel(FullPwArgs a) {
   const int tasks = a.n * bundles;
   const uint32_t cap = (uint32_t)a.n * (uint32_t)a.H * (uint32_t)a.W;
   bool out_of_range = false;
-  for (int t = blockIdx.y * nwaves + wave; t < tasks; t += gridDim.y * nwaves) {
-    const int n = t / bundles, y0 = (t % bundles) * rpw, y = y0 + r;
+  const bool check_range = red[15] != 0.f;               // (block-uniform; false for any sane BatchNorm)
+#ifdef TT_FULLPW_STAMP
+  const bool stamping = blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0;
+  unsigned long long stamp_t = 10ull * __builtin_amdgcn_s_memrealtime();
+#endif
+  for (int t = blockIdx.y * nwaves + wave; t < ((kPwSkip & 1) ? 0 : tasks); t += gridDim.y * nwaves) {
+    PW_STAMP(5);
+    // (the quotient of two wave-uniform values comes out of the vector unit: tell the compiler it is uniform)
+    const int n = __builtin_amdgcn_readfirstlane(t / bundles), y0 = __builtin_amdgcn_readfirstlane((t % bundles) * rpw), y = y0 + r;
     const bool live = r < rpw && y < a.H;
-    uint32_t in = 0;                                     // this lane's pixel: its 30 input bits
-    if (live)
+    // this lane's pixel: its 30 input bits.  Thirty loads off wave-uniform bases (the lane's part of the address
+    // is its row inside the bundle), issued together; written with a branch per channel they were issued and
+    // waited for one by one, which was most of a task's time.
+    uint32_t in = 0;
+    if constexpr (kPwSkip & 2) in = (uint32_t)(lane * 0x9E3779B1u + t) & 0x3FFFFFFFu;
+    else {
+      const int rc = live ? r : 0;
+      uint64_t rows[CIN];
+      const uint64_t *s0 = a.src[0], *s1 = a.src[1], *s2 = a.src[2], *s3 = a.src[3];
+      const size_t img = (size_t)n * a.Csrc * a.H + y0 + rc;     // (the only 64-bit product of the task)
 #pragma unroll
       for (int j = 0; j < CIN; ++j) {
-        const int J = CIN * g + j;
-        const uint64_t row = a.interleaved ? a.src[J & 3][((size_t)n * a.Csrc + (J >> 2)) * a.H + y]
-                                           : a.src[0][((size_t)n * a.Csrc + J) * a.H + y];
-        in |= (uint32_t)((row >> x) & 1ull) << j;
+        const int J = CIN * g + j;                       // (wave-uniform)
+        const int k = J & 3;
+        const uint64_t *sk = k == 0 ? s0 : (k == 1 ? s1 : (k == 2 ? s2 : s3));
+        rows[j] = a.interleaved ? sk[img + (uint32_t)((J >> 2) * a.H)] : s0[img + (uint32_t)(J * a.H)];
       }
+#pragma unroll
+      for (int j = 0; j < CIN; ++j) in |= (uint32_t)((rows[j] >> x) & 1ull) << j;
+      in = live ? in : 0u;
+    }
     // layer-1 B fragments: lane l of pixel tile nt = input bits 8 (l/16) .. + 7 of pixel 16 nt + l%16, as fp16 0 / 1
     uint4 xb[4];
 #pragma unroll
@@ -568,39 +637,66 @@ __global__ __launch_bounds__(512) void full_pw_fast_kernel(FullPwArgs a) {
     for (int ot = 0; ot < OT; ++ot)
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt) acc[ot][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    PW_STAMP(0);
 #pragma unroll 1
     for (int kp = 0; kp < KP; ++kp) {
       uint32_t g1[4][4], g2[4][4];                     // [pixel tile][dword]: high / low halves of 16 g, slots (0,1) (2,3) (4,5) (6,7)
 #pragma unroll
       for (int hf = 0; hf < 2; ++hf) {
         const int mt = 2 * kp + hf;
-        if (mt < MT) {
+        if ((kPwSkip & 4) == 0 && mt < MT) {
           const f16x8 wa = __builtin_bit_cast(f16x8, w1f[(mt * 2 + 0) * 64 + lane]), wb = __builtin_bit_cast(f16x8, w1f[(mt * 2 + 1) * 64 + lane]);
           const f32x4 sc = *(const f32x4 *)(s1f + 16 * mt + 4 * lg), sh = *(const f32x4 *)(t1f + 16 * mt + 4 * lg);
+          // All four pixel tiles of the hidden tile at once: eight matrix instructions, then sixteen independent
+          // BatchNorm / node computations, sixteen table reads in flight, sixteen evaluations.  (Tile by tile, every
+          // step waited for the one before: 150 cycles per value with two waves per SIMD.)
+          f32x4 d[4];
 #pragma unroll
-          for (int nt = 0; nt < 4; ++nt) {
-            const f16x8 xf = __builtin_bit_cast(f16x8, xb[nt]);
-            f32x4 d = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb, xf, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-            d = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa, xf, d, 0, 0, 0);
-            uint16_t hh[4], hl[4];
+          for (int nt = 0; nt < 4; ++nt) d[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb, __builtin_bit_cast(f16x8, xb[nt]), f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+#pragma unroll
+          for (int nt = 0; nt < 4; ++nt) d[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa, __builtin_bit_cast(f16x8, xb[nt]), d[nt], 0, 0, 0);
+          float zs[16], dz[16];
+          int node[16];
+#pragma unroll
+          for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
             for (int i = 0; i < 4; ++i) {               // register i = hidden unit 16 mt + 4 (l/16) + i
-              const float gv = gelu_f32(fmaf(d[i], sc[i], sh[i])) * ACT_PRESCALE;
-              out_of_range |= split_out_of_range(gv);
-              split_halves(gv, hh[i], hl[i]);
+              zs[4 * nt + i] = fmaf(d[nt][i], sc[i], sh[i]);
+              node[4 * nt + i] = gelu_node<(int)ACT_PRESCALE>(zs[4 * nt + i], dz[4 * nt + i]);
             }
-            g1[nt][2 * hf] = (uint32_t)hh[0] | ((uint32_t)hh[1] << 16);
-            g1[nt][2 * hf + 1] = (uint32_t)hh[2] | ((uint32_t)hh[3] << 16);
-            g2[nt][2 * hf] = (uint32_t)hl[0] | ((uint32_t)hl[1] << 16);
-            g2[nt][2 * hf + 1] = (uint32_t)hl[2] | ((uint32_t)hl[3] << 16);
-          }
+          float4 cf[16];
+#pragma unroll
+          for (int e = 0; e < 16; ++e) cf[e] = phi[node[e]];
+          float gv[16];
+#pragma unroll
+          for (int e = 0; e < 16; ++e) gv[e] = gelu_eval(zs[e], dz[e], cf[e]);
+          if (check_range)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) out_of_range |= split_out_of_range(gv[e]);
+          // high and low halves, two values per conversion (v_cvt_pk_f16_f32)
+          typedef float f32x2 __attribute__((ext_vector_type(2)));
+          typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+          for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+            for (int pr = 0; pr < 2; ++pr) {
+              const f32x2 v = {gv[4 * nt + 2 * pr], gv[4 * nt + 2 * pr + 1]};
+              const f16x2 hi = __builtin_convertvector(v, f16x2);
+              f32x2 rest;
+              rest.x = v.x - (float)hi.x;
+              rest.y = v.y - (float)hi.y;
+              const f16x2 lo = __builtin_convertvector(rest, f16x2);
+              g1[nt][2 * hf + pr] = __builtin_bit_cast(uint32_t, hi);
+              g2[nt][2 * hf + pr] = __builtin_bit_cast(uint32_t, lo);
+            }
         } else {
 #pragma unroll
           for (int nt = 0; nt < 4; ++nt) g1[nt][2 * hf] = g1[nt][2 * hf + 1] = g2[nt][2 * hf] = g2[nt][2 * hf + 1] = 0u;
         }
       }
+      PW_STAMP(1);
 #pragma unroll
-      for (int ot = 0; ot < OT; ++ot) {
+      for (int ot = 0; ot < ((kPwSkip & 8) ? 0 : OT); ++ot) {
         const f16x8 wa = __builtin_bit_cast(f16x8, w2f[((kp * OT + ot) * 2 + 0) * 64 + lane]);
         const f16x8 wb = __builtin_bit_cast(f16x8, w2f[((kp * OT + ot) * 2 + 1) * 64 + lane]);
 #pragma unroll
@@ -614,6 +710,11 @@ __global__ __launch_bounds__(512) void full_pw_fast_kernel(FullPwArgs a) {
           acc[ot][nt] = c;
         }
       }
+    }
+    PW_STAMP(2);
+    if constexpr (kPwSkip & 16) {
+      if (acc[0][0][0] == 123.456f) a.out_rp[t] = in;
+      continue;
     }
     // acc[ot][nt][i] = output channel 16 ot + 4 (l/16) + i at pixel 16 nt + l%16
     uint32_t doubt = 0;                                  // bit nt: some output of this lane at pixel tile nt is inside its bound
@@ -648,7 +749,8 @@ __global__ __launch_bounds__(512) void full_pw_fast_kernel(FullPwArgs a) {
             a.out_rp[((size_t)n * a.Cout + g * cout + o) * a.H + y0 + ln] = (mine >> (ln * a.W)) & ((1ull << a.W) - 1ull);
         }
       }
-    if (!a.out_float) {
+    PW_STAMP(3);
+    if (!a.out_float && !(kPwSkip & 32)) {
       // a pixel is listed if any of its channels (spread over the four lane groups) is in doubt
       uint32_t mine = 0;                                 // lanes 0-15: bit nt = pixel 16 nt + lane is listed
 #pragma unroll
@@ -676,7 +778,10 @@ __global__ __launch_bounds__(512) void full_pw_fast_kernel(FullPwArgs a) {
       const int wave_total = __shfl(total, 63);
       if (wave_total) {
         uint32_t base = 0;
-        if (lane == 0) base = atomicAdd(a.fix_count + g, (uint32_t)wave_total);
+        if (lane == 0) {
+          base = atomicAdd(a.fix_count + g, (uint32_t)wave_total);
+          atomicAdd(a.fix_count + 62, (uint32_t)wave_total);            // running total (ttnet_plan_query "full_listed_pw")
+        }
         base = (uint32_t)__shfl((int)base, 0);
         uint32_t k = base + (uint32_t)before;
 #pragma unroll
@@ -690,6 +795,132 @@ __global__ __launch_bounds__(512) void full_pw_fast_kernel(FullPwArgs a) {
     }
   }
   if (out_of_range && a.range_flag) *a.range_flag = 1u;
+}
+
+// ---- depthwise blocks: float32 tables and GELU, float64 where the sign is in doubt ---------------------------
+// The scheme of full_pw_fast_kernel for full_dw_tab_kernel: per-row partial sums from float32 tables (entries
+// rounded once from float64), float32 BatchNorm / GELU / second layer, and a bound tau on that evaluation's
+// error; an output with |pre| < tau goes on a list and full_dw_fix_kernel re-evaluates it in float64, in
+// full_dw_tab_kernel's order of summation, so the emitted bits are those of the float64 kernel.
+//     ez_m = |s1_m| A_m (2 KH) 2^-24 + 3 x 2^-24 zmax_m     table entries, KH-1 adds, the BatchNorm fma
+//     eg_m = 1.13 ez_m + 4e-7 (zmax_m + 0.1)
+//     E    = sum_m |w2_m| eg_m + 10 x 2^-24 sum_m |w2_m| zmax_m       eight fmas
+//     tau  = 2 (|s2| E + 2^-22 |t2|)
+// If the list overflows (it holds 1/16 of the outputs; about 1 in 10^5 is listed) the fix kernel recomputes
+// every output instead.
+template <int KH, int KW>
+__global__ __launch_bounds__(256) void full_dw_fast_kernel(FullDwArgs a) {
+  __shared__ float tab[8][KH][1 << KW];
+  __shared__ float s1f[8], t1f[8], w2f[8], s2f, t2f, tauf;
+  __shared__ float4 phi[kPhiN];
+  __shared__ double erf_tab[kErfN * kErfC];
+  erf_table_to_lds(erf_tab);
+  const int c = blockIdx.x;
+  constexpr int nk = KH * KW;
+  for (int i = threadIdx.x; i < 8 * KH * (1 << KW); i += blockDim.x) {
+    const int bits = i & ((1 << KW) - 1), kh = (i >> KW) % KH, m = i / (KH << KW);
+    double sum = 0.0;
+#pragma unroll
+    for (int kw = 0; kw < KW; ++kw) sum += ((bits >> kw) & 1) ? (double)a.w1[(size_t)c * 8 * nk + m * nk + kh * KW + kw] : 0.0;
+    tab[m][kh][bits] = (float)sum;
+  }
+  __syncthreads();
+  phi_table_to_lds(phi, erf_tab, 1.0);
+  if (threadIdx.x == 0) {
+    double E = 0.0, S2 = 0.0;
+    for (int m = 0; m < 8; ++m) {
+      double A = 0.0;
+      for (int k = 0; k < nk; ++k) A += fabs((double)a.w1[(size_t)c * 8 * nk + m * nk + k]);
+      const double sc = a.s1[c * 8 + m], sh = a.t1[c * 8 + m], w = (double)a.w2[c * 8 + m];
+      const double zmax = fabs(sc) * A + fabs(sh);
+      const double ez = fabs(sc) * A * (2.0 * KH) * 5.9604644775390625e-8 + 3.0 * 5.9604644775390625e-8 * zmax;
+      E += fabs(w) * (1.13 * ez + 4e-7 * (zmax + 0.1));
+      S2 += fabs(w) * zmax;
+      s1f[m] = (float)sc;
+      t1f[m] = (float)sh;
+      w2f[m] = (float)w;
+    }
+    E += 10.0 * 5.9604644775390625e-8 * S2;
+    s2f = (float)a.s2[c];
+    t2f = (float)a.t2[c];
+    tauf = (float)(2.0 * (fabs(a.s2[c]) * E + 2.384185791015625e-7 * fabs(a.t2[c])));
+  }
+  __syncthreads();
+  const int rows = a.n * a.ho;
+  const uint32_t cap = a.fix_cap;
+  for (int t = blockIdx.y * blockDim.x + threadIdx.x; t < rows; t += gridDim.y * blockDim.x) {
+    const int n = t / a.ho, oy = t % a.ho;
+    uint64_t r[KH];
+#pragma unroll
+    for (int kh = 0; kh < KH; ++kh) {
+      const int iy = oy * a.stride - a.pad + kh;
+      r[kh] = (iy >= 0 && iy < a.H) ? a.x_rp[((size_t)n * a.C + c) * a.H + iy] << a.pad : 0ull;   // bit 0 = column -pad
+    }
+    uint64_t out = 0, doubt = 0;
+    for (int ox = 0; ox < a.wo; ++ox) {
+      uint32_t idx[KH];
+#pragma unroll
+      for (int kh = 0; kh < KH; ++kh) idx[kh] = (uint32_t)(r[kh] >> (ox * a.stride)) & ((1u << KW) - 1u);
+      float acc = 0.f;
+#pragma unroll
+      for (int m = 0; m < 8; ++m) {
+        float sm = tab[m][0][idx[0]];
+#pragma unroll
+        for (int kh = 1; kh < KH; ++kh) sm += tab[m][kh][idx[kh]];
+        acc = fmaf(gelu_f32<1>(fmaf(sm, s1f[m], t1f[m]), phi), w2f[m], acc);
+      }
+      const float pre = fmaf(acc, s2f, t2f);
+      out |= (uint64_t)(pre >= 0.f) << (ox + a.pad_l);
+      doubt |= (uint64_t)(!(__builtin_fabsf(pre) >= tauf)) << ox;
+    }
+    a.out[((size_t)n * a.C + c) * a.Ho + oy + a.pad_t] = out;
+    while (doubt) {                                      // (rare)
+      const int ox = __builtin_ctzll(doubt);
+      doubt &= doubt - 1;
+      const uint32_t k = atomicAdd(a.fix_count, 1u);
+      atomicAdd(a.fix_count + 63, 1u);                   // running total (ttnet_plan_query "full_listed_dw")
+      if (k < cap) a.fix_list[k] = (((uint32_t)n * (uint32_t)a.C + (uint32_t)c) * (uint32_t)a.ho + (uint32_t)oy) * (uint32_t)a.wo + (uint32_t)ox;
+    }
+  }
+}
+
+// the listed outputs (or, after an overflow of the list, all of them) in float64: thread = one output
+__global__ __launch_bounds__(256) void full_dw_fix_kernel(FullDwArgs a) {
+  __shared__ double erf_tab[kErfN * kErfC];
+  const uint32_t listed = *a.fix_count;
+  const bool all = listed > a.fix_cap;
+  const uint32_t total = (uint32_t)a.n * (uint32_t)a.C * (uint32_t)a.ho * (uint32_t)a.wo;
+  const uint32_t work = all ? total : listed;
+  if (blockIdx.x * blockDim.x >= work) return;
+  erf_table_to_lds(erf_tab);
+  __syncthreads();
+  const int nk = a.kh * a.kw;
+  for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < work; t += gridDim.x * blockDim.x) {
+    const uint32_t id = all ? t : a.fix_list[t];
+    const int ox = (int)(id % (uint32_t)a.wo), oy = (int)((id / (uint32_t)a.wo) % (uint32_t)a.ho);
+    const int c = (int)((id / (uint32_t)(a.wo * a.ho)) % (uint32_t)a.C), n = (int)(id / (uint32_t)(a.wo * a.ho * a.C));
+    uint32_t win[6];
+    for (int kh = 0; kh < a.kh; ++kh) {
+      const int iy = oy * a.stride - a.pad + kh;
+      const uint64_t row = (iy >= 0 && iy < a.H) ? a.x_rp[((size_t)n * a.C + c) * a.H + iy] << a.pad : 0ull;
+      win[kh] = (uint32_t)(row >> (ox * a.stride)) & ((1u << a.kw) - 1u);
+    }
+    double acc = 0.0;
+    for (int m = 0; m < 8; ++m) {
+      // full_dw_tab_kernel's order: the taps of a row kw-ascending, then the rows kh-ascending
+      double sm = 0.0;
+      for (int kh = 0; kh < a.kh; ++kh) {
+        double part = 0.0;
+        for (int kw = 0; kw < a.kw; ++kw) part += ((win[kh] >> kw) & 1u) ? (double)a.w1[(size_t)c * 8 * nk + m * nk + kh * a.kw + kw] : 0.0;
+        sm = kh == 0 ? part : sm + part;
+      }
+      acc = fma(gelu_exact(sm * a.s1[c * 8 + m] + a.t1[c * 8 + m], erf_tab), (double)a.w2[c * 8 + m], acc);
+    }
+    const double pre = acc * a.s2[c] + a.t2[c];
+    unsigned long long *word = (unsigned long long *)(a.out + ((size_t)n * a.C + c) * a.Ho + oy + a.pad_t);
+    if (pre >= 0.0) atomicOr(word, 1ull << (ox + a.pad_l));
+    else atomicAnd(word, ~(1ull << (ox + a.pad_l)));
+  }
 }
 
 // act(AvgPool2d(2)(x) - 0.5): floor-cropped 2x2 majority on row-packed planes, placed at (pad_t, pad_l)
@@ -724,6 +955,13 @@ __global__ void full_pool_split_kernel(const float *x, uint16_t *feat_frag, int 
 
 }  // namespace
 
+// TTNET_FULL_EXACT=1: every output in float64 (the round-1 path; what the fast path is tested against).  Read at every
+// launch, so that a test can switch it between two forwards of one process (a captured graph keeps what it captured).
+static bool full_exact_only() {
+  const char *e = getenv("TTNET_FULL_EXACT");
+  return e && e[0] == '1';
+}
+
 int launch_full_dw(const FullDwArgs &a, hipStream_t s) {
   if (a.kh > 6 || a.kw > 6 || a.kh * a.kw > 36 || a.W + 2 * a.pad > 63) {
     set_error("full_dw: unsupported window %dx%d", a.kh, a.kw);
@@ -731,20 +969,20 @@ int launch_full_dw(const FullDwArgs &a, hipStream_t s) {
   }
   const int rows = a.n * a.ho;
   const int chunks = std::max(1, std::min((rows + 255) / 256, std::max(1, 1024 / a.C)));
+  const bool w65 = a.kh == 6 && a.kw == 5, w56 = a.kh == 5 && a.kw == 6;
+  if (!full_exact_only() && (w65 || w56) && a.fix_list && a.fix_count && a.fix_cap) {
+    TT_HIP(hipMemsetAsync(a.fix_count, 0, sizeof(uint32_t), s));
+    if (w65) hipLaunchKernelGGL((full_dw_fast_kernel<6, 5>), dim3(a.C, chunks), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((full_dw_fast_kernel<5, 6>), dim3(a.C, chunks), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(full_dw_fix_kernel, dim3(1024), dim3(256), 0, s, a);
+    TT_HIP(hipGetLastError());
+    return TTNET_OK;
+  }
   if (a.kh == 6 && a.kw == 5) hipLaunchKernelGGL((full_dw_tab_kernel<6, 5>), dim3(a.C, chunks), dim3(256), 0, s, a);
   else if (a.kh == 5 && a.kw == 6) hipLaunchKernelGGL((full_dw_tab_kernel<5, 6>), dim3(a.C, chunks), dim3(256), 0, s, a);
   else hipLaunchKernelGGL(full_dw_kernel, dim3(a.C, chunks), dim3(256), 0, s, a);
   TT_HIP(hipGetLastError());
   return TTNET_OK;
-}
-
-// TTNET_FULL_EXACT=1: every output in float64 (the round-1 path; what the fast path is tested against)
-static bool full_exact_only() {
-  static const bool v = [] {
-    const char *e = getenv("TTNET_FULL_EXACT");
-    return e && e[0] == '1';
-  }();
-  return v;
 }
 
 int launch_full_pw(const FullPwArgs &a, hipStream_t s) {
@@ -753,9 +991,9 @@ int launch_full_pw(const FullPwArgs &a, hipStream_t s) {
     const size_t lds = sizeof(double) * ((size_t)15 * 8 * 64 + (size_t)15 * 4 * ot * 64 + 2 * 240);
     const int rpw = 64 / a.W, tasks = a.n * ((a.H + rpw - 1) / rpw);
     const int chunks = std::max(1, std::min((tasks + 7) / 8, std::max(1, 512 / a.groups)));
-    const bool fast = !full_exact_only() && (a.out_float || (a.fix_list && a.fix_count)) && a.groups <= 64;
+    const bool fast = !full_exact_only() && (a.out_float || (a.fix_list && a.fix_count)) && a.groups <= 62;
     if (fast) {
-      if (!a.out_float) TT_HIP(hipMemsetAsync(a.fix_count, 0, 64 * sizeof(uint32_t), s));
+      if (!a.out_float) TT_HIP(hipMemsetAsync(a.fix_count, 0, 62 * sizeof(uint32_t), s));
       // two workgroups per CU (64 KiB of fragments each)
       const int fchunks = std::max(1, std::min((tasks + 7) / 8, std::max(1, 512 / a.groups)));
       if (ot == 2) {

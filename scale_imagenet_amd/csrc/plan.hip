@@ -706,6 +706,11 @@ int run_full_block(ttnet_plan *pl, size_t i, int n, hipStream_t s) {
     a.w1 = wts(b, ".conv1.weight"); a.w2 = wts(b, ".conv2.weight");
     a.s1 = b.s1; a.t1 = b.t1; a.s2 = b.s2; a.t2 = b.t2;
     a.out = o64[br];
+    if (pl->full_fix) {                                // (the list area is shared with the 1x1 blocks: launches are ordered)
+      a.fix_count = pl->full_fix;
+      a.fix_list = pl->full_fix + 64;
+      a.fix_cap = (uint32_t)std::min<size_t>(pl->full_fix_cap, 0x7FFFFFFFu);
+    }
     static const char *const kDw[2][4] = {{"full.conv1.f4", "full.conv1.f5", "full.conv1.f6", "full.conv1.f7"},
                                          {"full.conv2.f4", "full.conv2.f5", "full.conv2.f6", "full.conv2.f7"}};
     TT_TIMED(pl, kDw[br][std::min<size_t>(i, 3)], s, launch_full_dw(a, s));
@@ -1521,6 +1526,15 @@ int ttnet_plan_query(ttnet_plan *pl, const char *what, int64_t *out) {
     *pl->range_host = 0u;
   }
   else if (w == "lanes") *out = (int64_t)pl->lanes.size();
+  else if (w == "full_listed_pw" || w == "full_listed_dw") {      // full variant: (pixel, group) pairs / outputs sent to float64 so far (current lane)
+    uint32_t v[2] = {0, 0};
+    if (pl->full_fix) {
+      TT_HIP(hipSetDevice(pl->device));
+      TT_HIP(hipDeviceSynchronize());
+      TT_HIP(hipMemcpy(v, pl->full_fix + 62, sizeof(v), hipMemcpyDeviceToHost));
+    }
+    *out = v[w == "full_listed_dw" ? 1 : 0];
+  }
   else if (w.rfind("near_ties:", 0) == 0) {
     BlockTT *b = find_block(pl, w.c_str() + 10);
     if (!b) {

@@ -280,6 +280,9 @@ struct FullDwArgs {
   const float *w1, *w2;     // conv1.weight [8C][kh*kw], conv2.weight [C][8]
   const double *s1, *t1, *s2, *t2;
   uint64_t *out;            // [n][C][Ho]
+  // fast evaluation (gate_full.hip: full_dw_fast_kernel): the outputs whose sign float32 cannot vouch for
+  uint32_t *fix_list, *fix_count;   // ids of up to fix_cap outputs; one counter
+  uint32_t fix_cap;
 };
 struct FullPwArgs {
   int n, H, W;              // pixel grid

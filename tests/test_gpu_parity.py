@@ -833,3 +833,39 @@ def test_valexnet_config5(dev):
     if len(d) == 0:
         assert np.abs(y - y2).max() == 0.0
     assert np.array_equal(m.read_stage("flatten", 2)[0], taps["features.5"].numpy().reshape(n, -1)[0])
+
+
+def test_full_fast_path_is_the_float64_path(dev, monkeypatch):
+    """Full variant (fan-in 30): the grouped 1x1 and depthwise blocks are evaluated in split-fp16 / float32 and
+    only the outputs inside the evaluation's error bound are redone in float64 (gate_full.hip).  The emitted
+    bits must be exactly those of the all-float64 path (TTNET_FULL_EXACT=1) -- on every stage of a batch large
+    enough that thousands of outputs go through the float64 pass -- and a share of the outputs, but not most
+    of them, must have been listed."""
+    spec, st = spec_and_state("full")
+    m = ttnet.TT_vf_19lv3_imgnet(args_for("full"))
+    m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in st.items()})
+    m = m.to(dev).eval().reserve(24)
+    x = torch.from_numpy(synth.synth_images(24)).to(dev)
+    stages = [b.name for b in spec.blocks[:-1]]
+
+    def run():
+        with torch.no_grad():
+            y = m(x).cpu().numpy()
+        return y, {s: m.read_stage(s, 24).copy() for s in stages}
+
+    monkeypatch.delenv("TTNET_FULL_EXACT", raising=False)
+    plan_before = None
+    y_fast, st_fast = run()
+    plan_before = m._any_plan()
+    listed_pw, listed_dw = plan_before.query("full_listed_pw"), plan_before.query("full_listed_dw")
+    monkeypatch.setenv("TTNET_FULL_EXACT", "1")
+    y_exact, st_exact = run()
+    assert plan_before.query("full_listed_pw") == listed_pw          # (the exact path lists nothing)
+    for s in stages:
+        assert np.array_equal(st_fast[s], st_exact[s]), s
+    # the last block's features are float32 in the fast path, float64 rounded once in the exact one
+    assert np.abs(y_fast - y_exact).max() <= LOGIT_TOL
+    pixel_groups = 24 * sum(b.conv3.groups * b.in_hw[0] * b.in_hw[1] + (0 if b.last else b.convf.groups * b.out_hw[0] * b.out_hw[1])
+                            for b in spec.blocks)
+    print(f"full: {listed_pw} of {pixel_groups} (pixel, group) pairs and {listed_dw} depthwise outputs redone in float64")
+    assert 0 < listed_pw < pixel_groups // 8 and 0 < listed_dw
