@@ -108,7 +108,9 @@ int ttnet_plan_finalize(ttnet_plan *plan, void *stream);
  * normalised ImageNet inputs span [-2.2, 2.7]).  A value outside the range, or a NaN, raises a sticky
  * flag from inside the kernel; since the forward is asynchronous, it is the NEXT call on the plan
  * (forward, read_stage) that fails with TTNET_E_RANGE, and keeps failing until
- * ttnet_plan_query("range_overflow") has read and cleared the flag. */
+ * ttnet_plan_query("range_overflow") has read and cleared the flag.
+ * Alignment.  x_dev must be 16-byte aligned (the stem reads it with 16-byte buffer loads; any tensor
+ * torch allocates is): TTNET_E_INVALID otherwise.  The uint8 input of ttnet_forward_u8 needs 4 bytes. */
 int ttnet_forward(ttnet_plan *plan, const float *x_dev, int64_t n, float *logits_dev, void *stream);
 
 /* Batches in flight.  A plan starts with one lane = one set of activation buffers; lanes share

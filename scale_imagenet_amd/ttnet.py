@@ -280,6 +280,8 @@ class _TTNetBase(nn.Module):
         if x.dtype != torch.float32:
             raise RuntimeError(f"expected float32 input, got {x.dtype}")
         x = x.contiguous()
+        if x.data_ptr() % 16:                 # a view into a larger buffer: the stem wants 16-byte alignment (ttnet.h)
+            x = x.clone()
         n = x.shape[0]
         plan = self._plan_for(x.device, n)
         out = torch.empty((n, self.spec.n_classes), device=x.device, dtype=torch.float32)
@@ -297,6 +299,8 @@ class _TTNetBase(nn.Module):
         if (not x_u8.is_cuda) or x_u8.dtype != torch.uint8 or x_u8.dim() != 4 or tuple(x_u8.shape[1:]) != (h, w, 3):
             raise RuntimeError(f"expected a uint8 HIP tensor [N,{h},{w},3], got {x_u8.dtype} {tuple(x_u8.shape)} on {x_u8.device}")
         x_u8 = x_u8.contiguous()
+        if x_u8.data_ptr() % 4:
+            x_u8 = x_u8.clone()
         n = x_u8.shape[0]
         plan = self._plan_for(x_u8.device, n)
         out = torch.empty((n, self.spec.n_classes), device=x_u8.device, dtype=torch.float32)

@@ -869,3 +869,21 @@ def test_full_fast_path_is_the_float64_path(dev, monkeypatch):
                             for b in spec.blocks)
     print(f"full: {listed_pw} of {pixel_groups} (pixel, group) pairs and {listed_dw} depthwise outputs redone in float64")
     assert 0 < listed_pw < pixel_groups // 8 and 0 < listed_dw
+
+
+def test_unaligned_input_view(small_model, dev):
+    """The stem reads the input with 16-byte loads (ttnet.h); a view that starts 4 bytes into a buffer still works through
+    the module (it is copied), and the raw C ABI refuses it loudly."""
+    import ctypes as C
+    x = torch.from_numpy(synth.synth_images(2)).to(dev)
+    flat = torch.empty(x.numel() + 1, device=dev)
+    flat[1:] = x.reshape(-1)
+    view = flat[1:].view_as(x)
+    assert view.data_ptr() % 16 == 4
+    with torch.no_grad():
+        assert torch.equal(small_model(view), small_model(x))
+    plan = small_model._any_plan()
+    out = torch.empty((2, 1000), device=dev)
+    lib = _lib.load()
+    st = lib.ttnet_forward(plan.handle, C.c_void_p(view.data_ptr()), 2, C.c_void_p(out.data_ptr()), None)
+    assert st == -1 and b"aligned" in lib.ttnet_last_error()
