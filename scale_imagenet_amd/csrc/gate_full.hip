@@ -578,7 +578,7 @@ __global__ __launch_bounds__(512, TT_FULLPW_MINWAVES) void full_pw_fast_kernel(F
         const double sc = a.s2[g * cout + o], sh = a.t2[g * cout + o];
         s2f[o] = (float)(sc / ((double)ws2 * (double)ACT_PRESCALE));
         t2f[o] = (float)sh;
-        tau[o] = (float)(2.0 * (fabs(sc) * E + 2.384185791015625e-7 * fabs(sh)));
+        tau[o] = (float)(2.0 * (fabs(sc) * E + 2.384185791015625e-7 * fabs(sh))) * a.tau_scale;
       } else {
         s2f[o] = 0.f; t2f[o] = -1.0f; tau[o] = 0.f;
       }
@@ -843,7 +843,7 @@ __global__ __launch_bounds__(256) void full_dw_fast_kernel(FullDwArgs a) {
     E += 10.0 * 5.9604644775390625e-8 * S2;
     s2f = (float)a.s2[c];
     t2f = (float)a.t2[c];
-    tauf = (float)(2.0 * (fabs(a.s2[c]) * E + 2.384185791015625e-7 * fabs(a.t2[c])));
+    tauf = (float)(2.0 * (fabs(a.s2[c]) * E + 2.384185791015625e-7 * fabs(a.t2[c]))) * a.tau_scale;
   }
   __syncthreads();
   const int rows = a.n * a.ho;
@@ -961,8 +961,16 @@ static bool full_exact_only() {
   const char *e = getenv("TTNET_FULL_EXACT");
   return e && e[0] == '1';
 }
+// TTNET_FULL_TAU_SCALE=<f>: multiplies the error bound of the fast path (tests measure its margin with f < 1)
+static float full_tau_scale() {
+  const char *e = getenv("TTNET_FULL_TAU_SCALE");
+  const float v = e ? (float)atof(e) : 1.0f;
+  return v > 0.f ? v : 1.0f;
+}
 
-int launch_full_dw(const FullDwArgs &a, hipStream_t s) {
+int launch_full_dw(const FullDwArgs &a_in, hipStream_t s) {
+  FullDwArgs a = a_in;
+  a.tau_scale = full_tau_scale();
   if (a.kh > 6 || a.kw > 6 || a.kh * a.kw > 36 || a.W + 2 * a.pad > 63) {
     set_error("full_dw: unsupported window %dx%d", a.kh, a.kw);
     return TTNET_E_UNSUPPORTED;
@@ -985,7 +993,9 @@ int launch_full_dw(const FullDwArgs &a, hipStream_t s) {
   return TTNET_OK;
 }
 
-int launch_full_pw(const FullPwArgs &a, hipStream_t s) {
+int launch_full_pw(const FullPwArgs &a_in, hipStream_t s) {
+  FullPwArgs a = a_in;
+  a.tau_scale = full_tau_scale();
   if (a.cin == 30 && a.mid == 240 && (a.cout == 30 || a.cout == 15) && a.W <= 64) {
     const int ot = a.cout == 30 ? 2 : 1;
     const size_t lds = sizeof(double) * ((size_t)15 * 8 * 64 + (size_t)15 * 4 * ot * 64 + 2 * 240);

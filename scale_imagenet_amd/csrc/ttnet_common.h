@@ -283,6 +283,7 @@ struct FullDwArgs {
   // fast evaluation (gate_full.hip: full_dw_fast_kernel): the outputs whose sign float32 cannot vouch for
   uint32_t *fix_list, *fix_count;   // ids of up to fix_cap outputs; one counter
   uint32_t fix_cap;
+  float tau_scale;          // as FullPwArgs
 };
 struct FullPwArgs {
   int n, H, W;              // pixel grid
@@ -297,6 +298,7 @@ struct FullPwArgs {
   // fast evaluation (gate_full.hip: full_pw_fast_kernel): the (pixel, group) pairs whose sign the split-fp16
   // evaluation cannot vouch for, [groups][n*H*W] pixel ids and [64] counters; the range flag of the plan
   uint32_t *fix_list, *fix_count, *range_flag;
+  float tau_scale;          // 1; TTNET_FULL_TAU_SCALE shrinks the bound to measure its margin (tests only)
 };
 int launch_full_dw(const FullDwArgs &a, hipStream_t s);
 int launch_full_pw(const FullPwArgs &a, hipStream_t s);
