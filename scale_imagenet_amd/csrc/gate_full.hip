@@ -245,9 +245,10 @@ __global__ __launch_bounds__(512) void full_pw_mfma_kernel(FullPwArgs a) {
   __shared__ double erf_tab[kErfN * kErfC];
   erf_table_to_lds(erf_tab);
   constexpr int CIN = 30, MT = 15, KS1 = 8;              // 240 hidden units, K = 30 padded to 32
+  constexpr int NTT = FIX ? 1 : 4;                       // pixel tiles of 16 per task (FIX: one, so that a short list still spreads over the chip)
   if constexpr (FIX) {                                   // nothing listed for this workgroup: skip the weight staging too
     const uint32_t capq = (uint32_t)a.n * (uint32_t)a.H * (uint32_t)a.W, cnt = min(a.fix_count[blockIdx.x], capq);
-    if (blockIdx.y * (blockDim.x >> 6) >= (cnt + 63u) / 64u) return;
+    if (blockIdx.y * (blockDim.x >> 6) >= (cnt + 15u) / 16u) return;
   }
   double *w1f = lds;                                     // [MT][KS1][64]
   double *w2f = w1f + MT * KS1 * 64;                     // [MT][4][OT][64]
@@ -273,14 +274,14 @@ __global__ __launch_bounds__(512) void full_pw_mfma_kernel(FullPwArgs a) {
   const int rpw = 64 / a.W, bundles = (a.H + rpw - 1) / rpw;
   const uint32_t cap = (uint32_t)a.n * (uint32_t)a.H * (uint32_t)a.W;
   const uint32_t listed = FIX ? min(a.fix_count[g], cap) : 0u;
-  const int tasks = FIX ? (int)((listed + 63u) / 64u) : a.n * bundles;
+  const int tasks = FIX ? (int)((listed + 15u) / 16u) : a.n * bundles;
   for (int t = blockIdx.y * nwaves + wave; t < tasks; t += gridDim.y * nwaves) {
     int n, y0, y, x, r;
     bool live;
     uint32_t pid = 0;
     if constexpr (FIX) {
-      live = (uint32_t)(64 * t + lane) < listed;
-      pid = live ? a.fix_list[(size_t)g * cap + 64 * t + lane] : 0u;
+      live = (uint32_t)(16 * t + ln) < listed;           // lane l and its three lane-group twins: listed pixel 16 t + l%16
+      pid = live ? a.fix_list[(size_t)g * cap + 16 * t + ln] : 0u;
       x = (int)(pid % (uint32_t)a.W);
       y = (int)((pid / (uint32_t)a.W) % (uint32_t)a.H);
       n = (int)(pid / (uint32_t)(a.W * a.H));
@@ -304,39 +305,39 @@ __global__ __launch_bounds__(512) void full_pw_mfma_kernel(FullPwArgs a) {
         in |= (uint32_t)((row >> x) & 1ull) << j;
       }
     // B fragments of layer 1: lane l of (k-step ks, pixel tile nt) = bit 4ks + l/16 of pixel 16nt + l%16
-    double xf[KS1][4];
+    double xf[KS1][NTT];
 #pragma unroll
-    for (int nt = 0; nt < 4; ++nt) {
-      const uint32_t inp = (uint32_t)__shfl((int)in, 16 * nt + ln) >> lg;
+    for (int nt = 0; nt < NTT; ++nt) {
+      const uint32_t inp = (FIX ? in : (uint32_t)__shfl((int)in, 16 * nt + ln)) >> lg;
 #pragma unroll
       for (int ks = 0; ks < KS1; ++ks) xf[ks][nt] = ((inp >> (4 * ks)) & 1u) ? 1.0 : 0.0;
     }
-    f64x4 acc[OT][4];
+    f64x4 acc[OT][NTT];
 #pragma unroll
     for (int ot = 0; ot < OT; ++ot)
 #pragma unroll
-      for (int nt = 0; nt < 4; ++nt) acc[ot][nt] = f64x4{0.0, 0.0, 0.0, 0.0};
+      for (int nt = 0; nt < NTT; ++nt) acc[ot][nt] = f64x4{0.0, 0.0, 0.0, 0.0};
     for (int mt = 0; mt < MT; ++mt) {
-      f64x4 d[4];
+      f64x4 d[NTT];
 #pragma unroll
-      for (int nt = 0; nt < 4; ++nt) d[nt] = f64x4{0.0, 0.0, 0.0, 0.0};
+      for (int nt = 0; nt < NTT; ++nt) d[nt] = f64x4{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
       for (int ks = 0; ks < KS1; ++ks) {
         const double wa = w1f[(mt * KS1 + ks) * 64 + lane];
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt) d[nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(wa, xf[ks][nt], d[nt], 0, 0, 0);
+        for (int nt = 0; nt < NTT; ++nt) d[nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(wa, xf[ks][nt], d[nt], 0, 0, 0);
       }
 #pragma unroll
       for (int i = 0; i < 4; ++i) {                       // register i = hidden unit 16mt + 4i + l/16
         const double sc = s1[16 * mt + 4 * i + lg], sh = t1[16 * mt + 4 * i + lg];
-        double h[4];
+        double h[NTT];
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt) h[nt] = gelu_exact(d[nt][i] * sc + sh, erf_tab);
+        for (int nt = 0; nt < NTT; ++nt) h[nt] = gelu_exact(d[nt][i] * sc + sh, erf_tab);
 #pragma unroll
         for (int ot = 0; ot < OT; ++ot) {
           const double wb = w2f[((mt * 4 + i) * OT + ot) * 64 + lane];
 #pragma unroll
-          for (int nt = 0; nt < 4; ++nt) acc[ot][nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(wb, h[nt], acc[ot][nt], 0, 0, 0);
+          for (int nt = 0; nt < NTT; ++nt) acc[ot][nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(wb, h[nt], acc[ot][nt], 0, 0, 0);
         }
       }
     }
@@ -349,21 +350,15 @@ __global__ __launch_bounds__(512) void full_pw_mfma_kernel(FullPwArgs a) {
         const bool o_ok = o < cout;
         const double sc = o_ok ? a.s2[g * cout + o] : 0.0, sh = o_ok ? a.t2[g * cout + o] : -1.0;
         if constexpr (FIX) {
-          // the value of (pixel tile nt, this lane) belongs to the pixel that lane 16 nt + l%16 was given
-#pragma unroll
-          for (int nt = 0; nt < 4; ++nt) {
-            const uint32_t pp = (uint32_t)__shfl((int)pid, 16 * nt + ln);
-            const bool there = (uint32_t)(64 * t + 16 * nt + ln) < listed;
-            const uint32_t px = pp % (uint32_t)a.W, py = (pp / (uint32_t)a.W) % (uint32_t)a.H, pn = pp / (uint32_t)(a.W * a.H);
-            if (o_ok && there) {
-              unsigned long long *word = (unsigned long long *)(a.out_rp + ((size_t)pn * a.Cout + g * cout + o) * a.H + py);
-              if (acc[ot][nt][i] * sc + sh >= 0.0) atomicOr(word, 1ull << px);
-              else atomicAnd(word, ~(1ull << px));
-            }
+          // this lane's value belongs to its own listed pixel
+          if (o_ok && live) {
+            unsigned long long *word = (unsigned long long *)(a.out_rp + ((size_t)n * a.Cout + g * cout + o) * a.H + y);
+            if (acc[ot][0][i] * sc + sh >= 0.0) atomicOr(word, 1ull << x);
+            else atomicAnd(word, ~(1ull << x));
           }
         } else if (a.out_float) {
 #pragma unroll
-          for (int nt = 0; nt < 4; ++nt) {
+          for (int nt = 0; nt < NTT; ++nt) {
             const int p = 16 * nt + ln, pr = p / a.W, px = p - pr * a.W, py = y0 + pr;
             const double pre = acc[ot][nt][i] * sc + sh;
             if (o_ok && pr < rpw && py < a.H)
@@ -371,9 +366,9 @@ __global__ __launch_bounds__(512) void full_pw_mfma_kernel(FullPwArgs a) {
           }
         } else {
           // one ballot per pixel tile: bits 16q .. 16q+15 = channel quartet member q over the tile's 16 pixels
-          uint64_t bal[4];
+          uint64_t bal[4] = {0, 0, 0, 0};
 #pragma unroll
-          for (int nt = 0; nt < 4; ++nt) bal[nt] = __ballot(acc[ot][nt][i] * sc + sh >= 0.0);
+          for (int nt = 0; nt < NTT; ++nt) bal[nt] = __ballot(acc[ot][nt][i] * sc + sh >= 0.0);
           // lane (q = l/16, row r' = l%16 < rpw) writes the row word of channel 16ot + 4i + q, image row y0 + r'
           const uint64_t mine = ((bal[0] >> (16 * lg)) & 0xFFFFull) | (((bal[1] >> (16 * lg)) & 0xFFFFull) << 16) |
                                 (((bal[2] >> (16 * lg)) & 0xFFFFull) << 32) | (((bal[3] >> (16 * lg)) & 0xFFFFull) << 48);
@@ -1015,9 +1010,9 @@ int launch_full_pw(const FullPwArgs &a_in, hipStream_t s) {
       }
       TT_HIP(hipGetLastError());
       if (a.out_float) return TTNET_OK;
-      // the listed pixels in float64: a grid that could take 1/16 of all pixels at one task per wave; workgroups
-      // without listed pixels leave at once
-      const int xchunks = std::max(1, std::min((tasks / 16 + 7) / 8, std::max(1, 256 / a.groups)));
+      // the listed pixels in float64, 16 per wave task: one workgroup per CU (its float64 fragments fill the LDS);
+      // workgroups without listed pixels leave at once
+      const int xchunks = std::max(1, std::min((tasks / 4 + 7) / 8, std::max(1, 256 / a.groups)));
       if (ot == 2) {
         TT_TRY(ensure_dynamic_lds((const void *)full_pw_mfma_kernel<2, true>, lds));
         hipLaunchKernelGGL((full_pw_mfma_kernel<2, true>), dim3(a.groups, xchunks), dim3(512), lds, s, a);
