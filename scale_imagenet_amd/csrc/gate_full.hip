@@ -392,9 +392,12 @@ __global__ __launch_bounds__(512) void full_pw_mfma_kernel(FullPwArgs a) {
 // the weights it stages): with A_m = sum_c |w1[m][c]|, zmax_m = |s1_m| A_m + |t1_m| (no hidden unit can exceed it),
 //     ez_m = |s1_m| A_m (2^-21 + 16 x 2^-24) + 3 x 2^-24 zmax_m       layer 1: operand split, accumulation, BatchNorm fma
 //     eg_m = 1.13 ez_m + 4e-7 (zmax_m + 0.1)                           GELU: its slope, its own error (below)
-//     E    = sum_m |w2[o][m]| eg_m + 3.1e-6 sum_m |w2[o][m]| zmax_m    layer 2: both operand splits, the dropped
+//     E    = sum_m |w2[o][m]| eg_m + 3.2e-6 sum_m |w2[o][m]| |g_m|     layer 2: both operand splits, the dropped
 //                                                                      low x low product, 32 roundings of the sum
 //     tau  = 2 (|s2_o| E + 2^-22 |t2_o|)                               factor 2: margin
+// The second sum of E is the pixel's own: one more matrix instruction per k-step on |w2| x |g| (the high halves
+// with their sign bits cleared, which under-states either factor by at most 2^-11: the 3.2 for 3.1) accumulates
+// it beside the outputs -- with the worst case |g_m| <= zmax_m in its place the list was twice as long.
 // On the synthetic model about 1 in 1000 (pixel, group) pairs is listed.  The last block emits relu'd float32
 // features for a float32 head (tolerance 1e-5 on the logits): it takes the fast evaluation as it stands.
 //
@@ -476,7 +479,7 @@ __device__ unsigned long long g_pw_stamps[8];        // ns spent by wave 0 of bl
 template <int OT>
 constexpr size_t fast_lds_bytes() {
   return (size_t)kFastMT * 2 * 64 * 16 + (size_t)kFastKP * OT * 2 * 64 * 16 + 4 * 256 * sizeof(float) + 3 * 32 * sizeof(float) + 64 +
-         (size_t)kPhiN * 16;
+         (size_t)kPhiN * 16 + 32 * sizeof(float) + (size_t)kFastKP * OT * 64 * 16;
 }
 
 template <int OT>      // 16-row output tiles: 2 (cout = 30) or 1 (cout = 15)
@@ -490,9 +493,11 @@ __global__ __launch_bounds__(512, TT_FULLPW_MINWAVES) void full_pw_fast_kernel(F
   uint4 *w2f = w1f + MT * 2 * 64;                               // [KP][OT][plane][lane]: layer-2 A fragments
   float *s1f = (float *)(w2f + KP * OT * 2 * 64);               // [256] BatchNorm1 scale / layer-1 prescale
   float *t1f = s1f + 256, *zmx = t1f + 256, *egm = zmx + 256;   // [256] each: shift; zmax_m; eg_m
-  float *s2f = egm + 256, *t2f = s2f + 32, *tau = t2f + 32;     // [32] each
-  float *red = tau + 32;                                        // [16] reductions
+  float *s2f = egm + 256, *t2f = s2f + 32, *tau = t2f + 32;     // [32] each (tau: the part of the bound that does not depend on the pixel)
+  float *tauk = tau + 32;                                       // [32] bound per unit of the accumulated |w2| x |g|
+  float *red = tauk + 32;                                       // [16] reductions
   float4 *phi = (float4 *)(red + 16);                           // [512] GELU table
+  uint4 *w2a = (uint4 *)(phi + kPhiN);                          // [KP][OT][lane]: |w2|, high halves, layer-2 fragment order
   __shared__ double erf_tab[kErfN * kErfC];
   erf_table_to_lds(erf_tab);
   const int g = blockIdx.x, cout = a.cout;
@@ -542,6 +547,7 @@ __global__ __launch_bounds__(512, TT_FULLPW_MINWAVES) void full_pw_fast_kernel(F
       split_halves(v, h1, h2);
       w2h[(((kp * OT + ot) * 2 + 0) * 64 + l) * 8 + j] = h1;
       w2h[(((kp * OT + ot) * 2 + 1) * 64 + l) * 8 + j] = h2;
+      ((uint16_t *)w2a)[((kp * OT + ot) * 64 + l) * 8 + j] = h1 & 0x7FFFu;
     }
     for (int m = threadIdx.x; m < 256; m += blockDim.x) {
       if (m < MID) {
@@ -569,13 +575,14 @@ __global__ __launch_bounds__(512, TT_FULLPW_MINWAVES) void full_pw_fast_kernel(F
           E += w * (double)egm[m];
           S2 += w * (double)zmx[m];
         }
-        E += 3.1e-6 * S2;
+        (void)S2;                                        // (the worst case of the sum the kernel now accumulates per pixel)
         const double sc = a.s2[g * cout + o], sh = a.t2[g * cout + o];
         s2f[o] = (float)(sc / ((double)ws2 * (double)ACT_PRESCALE));
         t2f[o] = (float)sh;
         tau[o] = (float)(2.0 * (fabs(sc) * E + 2.384185791015625e-7 * fabs(sh))) * a.tau_scale;
+        tauk[o] = (float)(2.0 * fabs(sc) * 3.2e-6 / ((double)ws2 * (double)ACT_PRESCALE)) * a.tau_scale;
       } else {
-        s2f[o] = 0.f; t2f[o] = -1.0f; tau[o] = 0.f;
+        s2f[o] = 0.f; t2f[o] = -1.0f; tau[o] = 0.f; tauk[o] = 0.f;
       }
     }
     __syncthreads();
@@ -627,11 +634,11 @@ __global__ __launch_bounds__(512, TT_FULLPW_MINWAVES) void full_pw_fast_kernel(F
       for (int k = 0; k < 4; ++k) d[k] = ((inp >> (2 * k)) & 1u) * 0x3C00u + ((inp >> (2 * k + 1)) & 1u) * 0x3C000000u;
       xb[nt] = make_uint4(d[0], d[1], d[2], d[3]);
     }
-    f32x4 acc[OT][4];
+    f32x4 acc[OT][4], accb[OT][4];                       // the outputs; sum |w2| |g| of each (scaled like the outputs)
 #pragma unroll
     for (int ot = 0; ot < OT; ++ot)
 #pragma unroll
-      for (int nt = 0; nt < 4; ++nt) acc[ot][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int nt = 0; nt < 4; ++nt) acc[ot][nt] = accb[ot][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
     PW_STAMP(0);
 #pragma unroll 1
     for (int kp = 0; kp < KP; ++kp) {
@@ -704,6 +711,15 @@ __global__ __launch_bounds__(512, TT_FULLPW_MINWAVES) void full_pw_fast_kernel(F
           c = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa, b1, c, 0, 0, 0);
           acc[ot][nt] = c;
         }
+        if (!a.out_float) {
+          const f16x8 wabs = __builtin_bit_cast(f16x8, w2a[(kp * OT + ot) * 64 + lane]);
+#pragma unroll
+          for (int nt = 0; nt < 4; ++nt) {
+            const f16x8 babs = __builtin_bit_cast(f16x8, make_uint4(g1[nt][0] & 0x7FFF7FFFu, g1[nt][1] & 0x7FFF7FFFu, g1[nt][2] & 0x7FFF7FFFu,
+                                                                     g1[nt][3] & 0x7FFF7FFFu));
+            accb[ot][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wabs, babs, accb[ot][nt], 0, 0, 0);
+          }
+        }
       }
     }
     PW_STAMP(2);
@@ -719,7 +735,7 @@ __global__ __launch_bounds__(512, TT_FULLPW_MINWAVES) void full_pw_fast_kernel(F
       for (int i = 0; i < 4; ++i) {
         const int o = 16 * ot + 4 * lg + i;              // this lane's channel of the quartet
         const bool o_ok = o < cout;
-        const float sc = s2f[o], sh = t2f[o], tb = tau[o];
+        const float sc = s2f[o], sh = t2f[o], tb = tau[o], tk = tauk[o];
         if (a.out_float) {
 #pragma unroll
           for (int nt = 0; nt < 4; ++nt) {
@@ -734,7 +750,7 @@ __global__ __launch_bounds__(512, TT_FULLPW_MINWAVES) void full_pw_fast_kernel(F
           for (int nt = 0; nt < 4; ++nt) {
             const float pre = fmaf(acc[ot][nt][i], sc, sh);
             bal[nt] = __ballot(pre >= 0.f);
-            doubt |= (o_ok && !(__builtin_fabsf(pre) >= tb)) ? (1u << nt) : 0u;      // (a NaN is in doubt too)
+            doubt |= (o_ok && !(__builtin_fabsf(pre) >= fmaf(accb[ot][nt][i], tk, tb))) ? (1u << nt) : 0u;      // (a NaN is in doubt too)
           }
           // bits 16 q .. 16 q + 15 of a ballot = channel 16 ot + 4 q + i over the tile's 16 pixels; lane (q, row r' = l%16 < rpw)
           // writes the row word of that channel, image row y0 + r'

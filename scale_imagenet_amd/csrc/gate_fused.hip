@@ -183,7 +183,7 @@ __global__ __launch_bounds__(kFT) void gate_block_kernel(FusedArgs a) {
   extern __shared__ __align__(16) uint8_t lds[];
   constexpr int W = H, WO = HO, HP = H / 2, WP = W / 2, PIX = HO * WO;
   constexpr int RG = (HO + 3) / 4;                     // groups of 4 output rows
-  constexpr int LPR = WO <= 16 ? 16 : 32, RPW = 64 / LPR, CHK = (HO + RPW - 1) / RPW;
+  constexpr int LPR = WO <= 16 ? 16 : 32, RPW = 64 / LPR;
   using TI = row_t<W>;
   using TOut = row_t<WO>;
   uint8_t *const buf0 = lds, *const buf1 = lds + kFBuf;

@@ -36,12 +36,17 @@
 //  * a wave finishes one unit (N-tile x its M-tile) at a time, 33 MFMAs on one accumulator, its
 //    fragments read two k-steps ahead; the sign/pack epilogue of a unit then runs beside the other
 //    wave's MFMAs;
-//  * a producer lane pools two pixels from two 16-byte loads and writes packed dwords;
-//  * items are handed out so that the row blocks of an image run at the same time on one XCD: the
-//    5-row halo of a block comes from that L2 instead of HBM a second time (speed only).
+//  * the BatchNorm shift is one more k-row (a block of constants in LDS, its weights shift / c): the
+//    accumulators start from an inline zero;
+//  * a producer lane pools two pixels from two 16-byte buffer loads (row offset in an SGPR, padding by
+//    the bounds check) and writes packed dwords; a row's registers are refilled as soon as it is split;
+//  * a workgroup walks a run of consecutive row blocks and copies the five tile rows two neighbours
+//    share inside LDS: no input byte is read twice.
 //
-// Bound: 16-bit MFMA (2.5 PFLOP/s dense) at 3 MFMA flops per algorithmic flop (3.6 with the
-// slot / row padding) beside the HBM stream of the float32 input; 29.5 MMAC/image.
+// Bound: 16-bit MFMA (2.5 PFLOP/s dense) at 3 MFMA flops per algorithmic flop (3.6 with the slot / row
+// padding) at the clock the chip holds under this load, beside the HBM stream of the float32 input;
+// 29.5 MMAC/image.  The kernel is power-limited: all-zero input runs the same cycles at 1.93 instead of
+// 1.52 GHz.
 
 #include <math.h>
 #include <string.h>
@@ -61,7 +66,6 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 constexpr int SR = 8;                   // output rows per item
 constexpr int NBLK = 56 / SR;           // row blocks (items) per image
 constexpr int TR = 2 * SR + 5;          // pooled rows in the tile
-constexpr int ROWS = 3 * TR;            // (c, r) rows of a tile
 constexpr int PITCH = 60;               // dwords per tile row: 120 fp16 = pooled columns -4 .. 115
 constexpr int LROWS = 64;                // rows a copy holds: the tile's 63 and a spare one (a producer wave owns 16)
 constexpr int COPY_DW = LROWS * PITCH + 32;  // one copy of a plane; the +32 puts copy 1 thirty-two banks from copy 0
@@ -189,7 +193,6 @@ __global__ __launch_bounds__(STEM_THREADS) void stem_pc_kernel(const void *__res
   // Border handling is a clamp of the load address plus a multiplier that is zero in the padding.
   const int colraw = min(max(4 * lane - 8, 0), W - 4);
   const bool col_ok = lane >= 2 && lane < 58;
-  const float colm = col_ok ? 0.25f * X_PRESCALE : 0.0f;      // average of four, prescale; 0 in the padding
   // A producer wave owns the (c, r) rows pw, pw+4, ...  All global loads of an item are issued at
   // once, one item ahead: they are in flight across the workgroup barrier and while the row words
   // of the previous item are emitted, so the HBM latency is not on the per-item critical path.
