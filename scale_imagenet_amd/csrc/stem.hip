@@ -117,10 +117,6 @@ constexpr int CONST_DW = LROWS * PITCH; // the constant block of the BatchNorm-s
 // tile row of (c,kh) row R = c*7 + kh (for the lane's output row 0)
 constexpr int tile_row(int R) { return (R / 7) * TR + R % 7; }
 
-struct __attribute__((packed, aligned(4))) U8x12 {
-  uint32_t a, b, c;
-};
-
 // Persistent producer / consumer kernel.  One workgroup per CU walks items (image, block of SR
 // output rows).  Producer waves stream the raw rows from HBM, pool them and write the two fp16
 // planes (two copies each) of the NEXT item's tile into the other half of an LDS double buffer;
@@ -190,69 +186,101 @@ __global__ __launch_bounds__(STEM_THREADS) void stem_pc_kernel(const void *__res
   // ---- producer side -----------------------------------------------------------------------
   // Tile column t = pooled image column t - 4.  Lane l < 60 makes dword l of a row = pooled pixels
   // 2l-4 and 2l-3 = raw columns 4l-8 .. 4l-5: one 16-byte load per raw row (12 bytes of uint8).
-  // Border handling is a clamp of the load address plus a multiplier that is zero in the padding.
-  const int colraw = min(max(4 * lane - 8, 0), W - 4);
+  // Loads are buffer loads -- lane offset in a VGPR, row offset in an SGPR, the second raw row in the
+  // immediate -- whose bounds check supplies the zero padding: a row outside the image loads with an empty
+  // buffer, a lane outside the row with an offset beyond any buffer.
   const bool col_ok = lane >= 2 && lane < 58;
-  // A producer wave owns the (c, r) rows pw, pw+4, ...  All global loads of an item are issued at
-  // once, one item ahead: they are in flight across the workgroup barrier and while the row words
-  // of the previous item are emitted, so the HBM latency is not on the per-item critical path.
-  static_assert(U8 || PROD_WAVES * 16 == LROWS, "float32 input: a producer wave owns 16 consecutive tile rows");
-  constexpr int RPW8 = (TR + PROD_WAVES - 1) / PROD_WAVES;           // U8: pooled rows per producer wave (6), 3 channels each
+  static_assert(PROD_WAVES * 16 == LROWS, "a producer wave owns 16 consecutive tile rows (float32) / 6 pooled rows (uint8)");
   float4 ra[U8 ? 1 : 16], rb[U8 ? 1 : 16];
-  U8x12 qa[U8 ? RPW8 : 1], qb[U8 ? RPW8 : 1];
-  bool out_of_range = false;             // a pooled, prescaled value beyond fp16 (|x| >= 4094): see split_out_of_range
+  typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
+  u32x3 qa[U8 ? 6 : 1], qb[U8 ? 6 : 1];
+  bool out_of_range = false;             // (a range overflow found outside the packed check below)
   const int pw = wave - CONS_WAVES;      // 0..3 (producers)
-  auto issue_loads = [&](int j) {             // uint8 input
-    int n, oy0;
-    item_of(j, n, oy0);
+  // rows 16..20 of the previous tile are rows 0..4 of this one: 3 channels x 5 rows x (2 planes x 2 copies),
+  // 240 bytes each, as 16-byte pieces, four row arrays per wave instruction
+  auto halo_copy = [&](int js, uint32_t *tile) {
+    const uint32_t *prev = tiles + ((js - 1) & 1) * TILE_DW;
+    const int piece = lane % 15, which = lane / 15;            // lanes 60-63 idle
+    if (which < 4) {
 #pragma unroll
-    for (int bi = 0; bi < RPW8; ++bi) {
-      const int r = pw + PROD_WAVES * bi;             // wave-uniform
-      const int iy = 2 * oy0 - 3 + r;
-      const bool row_ok = r < TR && iy >= 0 && iy < 112;
-      const uint8_t *src = xu8 + ((size_t)n * H + 2 * (row_ok ? iy : 0)) * (W * 3) + 3 * colraw;
-      qa[bi] = *(const U8x12 *)src;
-      qb[bi] = *(const U8x12 *)(src + W * 3);
-    }
-  };
-  auto split_tile = [&](int j, uint32_t *tile) {   // uint8 input
-    if constexpr (kStemSkip & 2) return;
-    if (lane >= PITCH) return;             // one exec mask for the whole tile, not one per row
-    int n, oy0;
-    item_of(j, n, oy0);
-    const uint32_t colk = col_ok ? 0xFFFFFFFFu : 0u;
-#pragma unroll
-    for (int bi = 0; bi < RPW8; ++bi) {
-      const int r = pw + PROD_WAVES * bi;
-      if (r < TR) {
-        const int iy = 2 * oy0 - 3 + r;
-        const uint32_t keep = (iy >= 0 && iy < 112) ? colk : 0u;     // zero padding after the normalisation
-        const U8x12 a = qa[bi], b = qb[bi];
-        // bytes of a raw row: a.a = r0 g0 b0 r1, a.b = g1 b1 r2 g2, a.c = b2 r3 g3 b3 (pixels 0,1 -> first pooled pixel)
-        uint32_t s0[3], s1[3];
-        s0[0] = __builtin_amdgcn_udot4(a.a, 0x01000001u, __builtin_amdgcn_udot4(b.a, 0x01000001u, 0u, false), false);
-        s0[1] = __builtin_amdgcn_udot4(a.a, 0x00000100u, __builtin_amdgcn_udot4(b.a, 0x00000100u, 0u, false), false) +
-                __builtin_amdgcn_udot4(a.b, 0x00000001u, __builtin_amdgcn_udot4(b.b, 0x00000001u, 0u, false), false);
-        s0[2] = __builtin_amdgcn_udot4(a.a, 0x00010000u, __builtin_amdgcn_udot4(b.a, 0x00010000u, 0u, false), false) +
-                __builtin_amdgcn_udot4(a.b, 0x00000100u, __builtin_amdgcn_udot4(b.b, 0x00000100u, 0u, false), false);
-        s1[0] = __builtin_amdgcn_udot4(a.b, 0x00010000u, __builtin_amdgcn_udot4(b.b, 0x00010000u, 0u, false), false) +
-                __builtin_amdgcn_udot4(a.c, 0x00000100u, __builtin_amdgcn_udot4(b.c, 0x00000100u, 0u, false), false);
-        s1[1] = __builtin_amdgcn_udot4(a.b, 0x01000000u, __builtin_amdgcn_udot4(b.b, 0x01000000u, 0u, false), false) +
-                __builtin_amdgcn_udot4(a.c, 0x00010000u, __builtin_amdgcn_udot4(b.c, 0x00010000u, 0u, false), false);
-        s1[2] = __builtin_amdgcn_udot4(a.c, 0x01000001u, __builtin_amdgcn_udot4(b.c, 0x01000001u, 0u, false), false);
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-          const uint32_t e0 = s_norm[c * 1024 + s0[c]] & keep, e1 = s_norm[c * 1024 + s1[c]] & keep;
-          const uint32_t d1 = __builtin_amdgcn_perm(e1, e0, 0x05040100u);      // h1 of both pixels
-          const uint32_t d2 = __builtin_amdgcn_perm(e1, e0, 0x07060302u);      // h2 of both pixels
-          uint32_t *dst = tile + (c * TR + r) * PITCH + lane;
-          dst[0] = d1;
-          dst[COPY_DW - 1] = d1;             // copy 1, one dword to the left (lane 0 lands in unused padding)
-          dst[PLANE_DW] = d2;
-          dst[PLANE_DW + COPY_DW - 1] = d2;
+      for (int k = 0; k < 4; ++k) {
+        const int id = 16 * pw + 4 * k + which;                 // 0..63, 60 used: (array, channel, row)
+        if (id < 60) {
+          const int arr = id / 15, cr5 = id - 15 * arr, c = cr5 / 5, rr = cr5 - 5 * c;
+          const int base = (arr >> 1) * PLANE_DW + (arr & 1) * COPY_DW + (c * TR + rr) * PITCH + 4 * piece;
+          const uint4 v = *(const uint4 *)(prev + base + 16 * PITCH);
+          *(uint4 *)(tile + base) = v;
         }
       }
     }
+  };
+  // uint8 input: a producer wave owns 6 consecutive pooled rows of a whole tile (21: the last wave 3), all three
+  // channels of each; an item that continues the previous one needs rows 5..20, 4 per wave.  One pass splits
+  // item js and refills each row's registers with the same row of item jl as soon as it has been split (the
+  // scheme of f32_pass below).
+  const uint32_t lane_off8 = col_ok ? (uint32_t)(12 * lane - 24) : 0x7FFF0000u;
+  auto u8_pass = [&](auto split_c, int js, int jl, uint32_t *tile) {
+    constexpr bool SPLIT = decltype(split_c)::value;
+    int ns = 0, oys = 0, nl = 0, oyl0 = 0;
+    if (SPLIT) item_of(js, ns, oys);
+    const bool load_ok = jl < my_items;
+    item_of(load_ok ? jl : 0, nl, oyl0);
+    const bool cont_s = SPLIT && continues(js), cont_l = load_ok && continues(jl);
+    const void *img = (const void *)(xu8 + (size_t)nl * (H * W * 3));
+    if (lane < PITCH) {
+      const uint32_t colk = col_ok ? 0xFFFFFFFFu : 0u;
+      auto split_row = [&](auto bic) {
+        constexpr int bi = decltype(bic)::value;
+        const int r = cont_s ? 5 + 4 * pw + bi : 6 * pw + bi;            // wave-uniform
+        if (r < TR) {
+          const int iy = 2 * oys - 3 + r;
+          const uint32_t keep = (iy >= 0 && iy < 112) ? colk : 0u;       // zero padding after the normalisation
+          const u32x3 a = qa[bi], b = qb[bi];
+          // bytes of a raw row: a.x = r0 g0 b0 r1, a.y = g1 b1 r2 g2, a.z = b2 r3 g3 b3 (pixels 0,1 -> first pooled pixel)
+          uint32_t s0[3], s1[3];
+          s0[0] = __builtin_amdgcn_udot4(a.x, 0x01000001u, __builtin_amdgcn_udot4(b.x, 0x01000001u, 0u, false), false);
+          s0[1] = __builtin_amdgcn_udot4(a.x, 0x00000100u, __builtin_amdgcn_udot4(b.x, 0x00000100u, 0u, false), false) +
+                  __builtin_amdgcn_udot4(a.y, 0x00000001u, __builtin_amdgcn_udot4(b.y, 0x00000001u, 0u, false), false);
+          s0[2] = __builtin_amdgcn_udot4(a.x, 0x00010000u, __builtin_amdgcn_udot4(b.x, 0x00010000u, 0u, false), false) +
+                  __builtin_amdgcn_udot4(a.y, 0x00000100u, __builtin_amdgcn_udot4(b.y, 0x00000100u, 0u, false), false);
+          s1[0] = __builtin_amdgcn_udot4(a.y, 0x00010000u, __builtin_amdgcn_udot4(b.y, 0x00010000u, 0u, false), false) +
+                  __builtin_amdgcn_udot4(a.z, 0x00000100u, __builtin_amdgcn_udot4(b.z, 0x00000100u, 0u, false), false);
+          s1[1] = __builtin_amdgcn_udot4(a.y, 0x01000000u, __builtin_amdgcn_udot4(b.y, 0x01000000u, 0u, false), false) +
+                  __builtin_amdgcn_udot4(a.z, 0x00010000u, __builtin_amdgcn_udot4(b.z, 0x00010000u, 0u, false), false);
+          s1[2] = __builtin_amdgcn_udot4(a.z, 0x01000001u, __builtin_amdgcn_udot4(b.z, 0x01000001u, 0u, false), false);
+#pragma unroll
+          for (int c = 0; c < 3; ++c) {
+            const uint32_t e0 = s_norm[c * 1024 + s0[c]] & keep, e1 = s_norm[c * 1024 + s1[c]] & keep;
+            const uint32_t d1 = __builtin_amdgcn_perm(e1, e0, 0x05040100u);      // h1 of both pixels
+            const uint32_t d2 = __builtin_amdgcn_perm(e1, e0, 0x07060302u);      // h2 of both pixels
+            uint32_t *dst = tile + (c * TR + r) * PITCH + lane;
+            dst[0] = d1;
+            dst[COPY_DW - 1] = d1;             // copy 1, one dword to the left (lane 0 lands in unused padding)
+            dst[PLANE_DW] = d2;
+            dst[PLANE_DW + COPY_DW - 1] = d2;
+          }
+        }
+      };
+      auto load_row = [&](auto bic) {
+        constexpr int bi = decltype(bic)::value;
+        const int r = cont_l ? 5 + 4 * pw + bi : 6 * pw + bi;
+        const int iy = 2 * oyl0 - 3 + r;
+        const bool row_ok = load_ok && r < TR && iy >= 0 && iy < 112;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)img, 0, row_ok ? H * W * 3 : 0, 0x00020000);
+        const int soff = row_ok ? 2 * iy * (W * 3) : 0;
+        qa[bi] = __builtin_amdgcn_raw_buffer_load_b96(rs, (int)lane_off8, soff, 0);
+        qb[bi] = __builtin_amdgcn_raw_buffer_load_b96(rs, (int)lane_off8 + W * 3, soff, 0);
+      };
+      static_for<0, 4>([&](auto bic) {
+        if constexpr (SPLIT && !(kStemSkip & 2)) split_row(bic);
+        load_row(bic);
+      });
+      // the two slots only a whole tile uses (the first item of a run or of an image)
+      if constexpr (SPLIT && !(kStemSkip & 2))
+        if (!cont_s) static_for<4, 6>([&](auto bic) { split_row(bic); });
+      if (!cont_l) static_for<4, 6>([&](auto bic) { load_row(bic); });
+    }
+    if (cont_s) halo_copy(js, tile);
   };
   // float32 input.  A producer wave owns 16 consecutive (c, r) rows of the tile (the 64th is a spare).
   // One pass splits item js and, row by row, refills each row's registers with the same row of item
@@ -337,24 +365,7 @@ __global__ __launch_bounds__(STEM_THREADS) void stem_pc_kernel(const void *__res
         if (!cont_s) static_for<12, 16>([&](auto bic) { split_row(bic); });
       if (!cont_l) static_for<12, 16>([&](auto bic) { load_row(bic); });
     }
-    // rows 16..20 of the previous tile are rows 0..4 of this one: 3 channels x 5 rows x (2 planes x 2 copies),
-    // 240 bytes each, as 16-byte pieces, four row arrays per wave instruction
-    if (cont_s) {
-      const uint32_t *prev = tiles + ((js - 1) & 1) * TILE_DW;
-      const int piece = lane % 15, which = lane / 15;            // lanes 60-63 idle
-      if (which < 4) {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          const int id = 16 * pw + 4 * k + which;                 // 0..63, 60 used: (array, channel, row)
-          if (id < 60) {
-            const int arr = id / 15, cr5 = id - 15 * arr, c = cr5 / 5, rr = cr5 - 5 * c;
-            const int base = (arr >> 1) * PLANE_DW + (arr & 1) * COPY_DW + (c * TR + rr) * PITCH + 4 * piece;
-            const uint4 v = *(const uint4 *)(prev + base + 16 * PITCH);
-            *(uint4 *)(tile + base) = v;
-          }
-        }
-      }
-    }
+    if (cont_s) halo_copy(js, tile);
   };
   // row words of a finished item from the pieces staged by the consumers
   auto emit_rows = [&](int j, const uint32_t (*st)[NT + 2]) {
@@ -467,29 +478,22 @@ __global__ __launch_bounds__(STEM_THREADS) void stem_pc_kernel(const void *__res
   if (producer) {
     if (TT_STEM_PRIO > 0) __builtin_amdgcn_s_setprio(TT_STEM_PRIO);
     STEM_STAMP(1, 0);
-    if constexpr (U8) {
-      if (my_items > 0) issue_loads(0);
-    } else {
-      if (my_items > 0) f32_pass(std::false_type{}, 0, 0, tiles);
+    if (my_items > 0) {
+      if constexpr (U8) u8_pass(std::false_type{}, 0, 0, tiles);
+      else f32_pass(std::false_type{}, 0, 0, tiles);
     }
     __syncthreads();
     STEM_STAMP(1, 1);
-    if constexpr (U8) {
-      if (my_items > 0) split_tile(0, tiles);
-      if (my_items > 1) issue_loads(1);
-    } else {
-      if (my_items > 0) f32_pass(std::true_type{}, 0, 1, tiles);
+    if (my_items > 0) {
+      if constexpr (U8) u8_pass(std::true_type{}, 0, 1, tiles);
+      else f32_pass(std::true_type{}, 0, 1, tiles);
     }
     STEM_STAMP(1, 2);
     __syncthreads();
     for (int j = 0; j < my_items; ++j) {
-      if constexpr (U8) {
-        // split first (its loads were issued most of a period ago), refill the load registers at
-        // once, and only then the row words of the previous item
-        if (j + 1 < my_items) split_tile(j + 1, tiles + ((j + 1) & 1) * TILE_DW);
-        if (j + 2 < my_items) issue_loads(j + 2);
-      } else {
-        if (j + 1 < my_items) f32_pass(std::true_type{}, j + 1, j + 2, tiles + ((j + 1) & 1) * TILE_DW);
+      if (j + 1 < my_items) {
+        if constexpr (U8) u8_pass(std::true_type{}, j + 1, j + 2, tiles + ((j + 1) & 1) * TILE_DW);
+        else f32_pass(std::true_type{}, j + 1, j + 2, tiles + ((j + 1) & 1) * TILE_DW);
       }
       if (j > 0) emit_rows(j - 1, stage[(j - 1) & 1]);
       STEM_STAMP(1, 3 + j);
