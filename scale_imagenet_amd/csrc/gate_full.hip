@@ -895,42 +895,61 @@ __global__ __launch_bounds__(256) void full_dw_fast_kernel(FullDwArgs a) {
   }
 }
 
-// the listed outputs (or, after an overflow of the list, all of them) in float64: thread = one output
+// the listed outputs (or, after an overflow of the list, all of them) in float64.  Eight lanes per output, one per
+// hidden unit (its 30 weight loads are independent and in flight together: one thread per output walked 240
+// dependent loads and took 54 us for a few thousand outputs); lane 0 of the eight then forms the second layer in
+// full_dw_tab_kernel's order.
 __global__ __launch_bounds__(256) void full_dw_fix_kernel(FullDwArgs a) {
   __shared__ double erf_tab[kErfN * kErfC];
   const uint32_t listed = *a.fix_count;
   const bool all = listed > a.fix_cap;
   const uint32_t total = (uint32_t)a.n * (uint32_t)a.C * (uint32_t)a.ho * (uint32_t)a.wo;
   const uint32_t work = all ? total : listed;
-  if (blockIdx.x * blockDim.x >= work) return;
+  if (blockIdx.x * (blockDim.x / 8) >= work) return;
   erf_table_to_lds(erf_tab);
   __syncthreads();
-  const int nk = a.kh * a.kw;
-  for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < work; t += gridDim.x * blockDim.x) {
-    const uint32_t id = all ? t : a.fix_list[t];
+  const int nk = a.kh * a.kw, m = threadIdx.x & 7;
+  for (uint32_t t0 = blockIdx.x * (blockDim.x / 8); t0 < work; t0 += gridDim.x * (blockDim.x / 8)) {
+    const uint32_t t = t0 + (threadIdx.x >> 3);
+    const bool live = t < work;                         // (whole groups of eight lanes)
+    const uint32_t id = live ? (all ? t : a.fix_list[t]) : 0u;
     const int ox = (int)(id % (uint32_t)a.wo), oy = (int)((id / (uint32_t)a.wo) % (uint32_t)a.ho);
     const int c = (int)((id / (uint32_t)(a.wo * a.ho)) % (uint32_t)a.C), n = (int)(id / (uint32_t)(a.wo * a.ho * a.C));
     uint32_t win[6];
-    for (int kh = 0; kh < a.kh; ++kh) {
+#pragma unroll
+    for (int kh = 0; kh < 6; ++kh) {
       const int iy = oy * a.stride - a.pad + kh;
-      const uint64_t row = (iy >= 0 && iy < a.H) ? a.x_rp[((size_t)n * a.C + c) * a.H + iy] << a.pad : 0ull;
+      const uint64_t row = (kh < a.kh && iy >= 0 && iy < a.H) ? a.x_rp[((size_t)n * a.C + c) * a.H + iy] << a.pad : 0ull;
       win[kh] = (uint32_t)(row >> (ox * a.stride)) & ((1u << a.kw) - 1u);
     }
-    double acc = 0.0;
-    for (int m = 0; m < 8; ++m) {
-      // full_dw_tab_kernel's order: the taps of a row kw-ascending, then the rows kh-ascending
-      double sm = 0.0;
-      for (int kh = 0; kh < a.kh; ++kh) {
+    // full_dw_tab_kernel's order: the taps of a row kw-ascending, then the rows kh-ascending
+    const float *w = a.w1 + (size_t)c * 8 * nk + (size_t)m * nk;
+    float wv[36];
+#pragma unroll
+    for (int k = 0; k < 36; ++k) wv[k] = k < nk ? w[k] : 0.f;
+    double sm = 0.0;
+#pragma unroll
+    for (int kh = 0; kh < 6; ++kh)
+      if (kh < a.kh) {
         double part = 0.0;
-        for (int kw = 0; kw < a.kw; ++kw) part += ((win[kh] >> kw) & 1u) ? (double)a.w1[(size_t)c * 8 * nk + m * nk + kh * a.kw + kw] : 0.0;
+#pragma unroll
+        for (int kw = 0; kw < 6; ++kw)
+          if (kw < a.kw) part += ((win[kh] >> kw) & 1u) ? (double)wv[kh * a.kw + kw] : 0.0;
         sm = kh == 0 ? part : sm + part;
       }
-      acc = fma(gelu_exact(sm * a.s1[c * 8 + m] + a.t1[c * 8 + m], erf_tab), (double)a.w2[c * 8 + m], acc);
+    const double gm = gelu_exact(sm * a.s1[c * 8 + m] + a.t1[c * 8 + m], erf_tab);
+    double acc = 0.0;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const double gq = __shfl(gm, (threadIdx.x & 56) + q);           // (the lane index inside the wave: 8 outputs per wave)
+      acc = fma(gq, (double)a.w2[c * 8 + q], acc);
     }
-    const double pre = acc * a.s2[c] + a.t2[c];
-    unsigned long long *word = (unsigned long long *)(a.out + ((size_t)n * a.C + c) * a.Ho + oy + a.pad_t);
-    if (pre >= 0.0) atomicOr(word, 1ull << (ox + a.pad_l));
-    else atomicAnd(word, ~(1ull << (ox + a.pad_l)));
+    if (live && m == 0) {
+      const double pre = acc * a.s2[c] + a.t2[c];
+      unsigned long long *word = (unsigned long long *)(a.out + ((size_t)n * a.C + c) * a.Ho + oy + a.pad_t);
+      if (pre >= 0.0) atomicOr(word, 1ull << (ox + a.pad_l));
+      else atomicAnd(word, ~(1ull << (ox + a.pad_l)));
+    }
   }
 }
 
