@@ -418,6 +418,14 @@ def main():
                 out["kernel_us_per_256_at_b2048"] = {k: round(v * 1e3 / 8.0, 2) for k, v in big.items()}
             if world == 1 and not args.no_extras:
                 out["parity"] = golden_parity(args.variant, spec, model, dev)
+            if args.variant == "full" and os.environ.get("TTNET_FULL_EXACT") != "1":
+                # share of the blocks' outputs the fast evaluation could not vouch for and sent through float64;
+                # counters of the plan's current lane since it was created
+                plan = model._any_plan()
+                out["full_fast_path"] = {"listed_pixel_groups_1x1": plan.query("full_listed_pw"),
+                                         "listed_outputs_depthwise": plan.query("full_listed_dw"),
+                                         "note": "running totals over every forward of this process on one lane; "
+                                                 "about 1.1 % of the (pixel, group) pairs and 1e-4 of the depthwise outputs"}
         except Exception as e:                      # noqa: BLE001 - reported, not swallowed
             out["extras_error"] = f"{type(e).__name__}: {e}"
         try:

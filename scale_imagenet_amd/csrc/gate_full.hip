@@ -438,6 +438,19 @@ __device__ inline int gelu_node(float zs, float &dz) {
   return (int)r + kPhiN / 2;
 }
 __device__ inline float gelu_eval(float zs, float dz, const float4 &c) { return zs * fmaf(dz, fmaf(dz, c.z, c.y), c.x); }
+// The node without a round, a convert and an index shift: t = 2^23 x 1.5 + (argument in units of 1/32) holds the
+// nearest node in its low mantissa bits (round to nearest even, like rint), so  t - magic  is the node as a float and
+// (bits of t) << 4 plus a constant is the byte address of its table entry.  d, sc2, sh2: the matrix instruction's
+// output and BatchNorm scale / shift pre-multiplied by 32 / SCALE (sh2 with the magic number added); zs = the same
+// value in units of 1 / SCALE.  Six vector instructions with gelu_eval's three.
+constexpr float kNodeMagic = 12582912.0f;            // 1.5 x 2^23
+template <int SCALE>
+__device__ inline uint32_t gelu_node_fast(float d, float sc2, float sh2m, float zs, float &dz, uint32_t addr_k) {
+  float t = fmaf(d, sc2, sh2m);
+  t = __builtin_fminf(__builtin_fmaxf(t, kNodeMagic - (float)(kPhiN / 2)), kNodeMagic + (float)(kPhiN / 2 - 1));
+  dz = fmaf(t - kNodeMagic, -(float)SCALE / 32.0f, zs);
+  return (__float_as_uint(t) << 4) + addr_k;
+}
 template <int SCALE>
 __device__ inline float gelu_f32(float zs, const float4 *tab) {
   float dz;
@@ -464,6 +477,7 @@ __device__ inline void split_halves(float v, uint16_t &h1, uint16_t &h2) {
 }
 
 constexpr int kFastMT = 15, kFastKP = 8, kFastMid = 240, kFastCin = 30;
+
 // tools/ubench/full_pw_parts.hip builds this file with parts of full_pw_fast_kernel switched off (bit mask:
 // 1 no tasks (staging only), 2 no input gather, 4 no layer 1 / GELU, 8 no layer 2, 16 no epilogue).  0 in the library.
 #ifndef TT_FULLPW_SKIP
@@ -479,7 +493,7 @@ __device__ unsigned long long g_pw_stamps[8];        // ns spent by wave 0 of bl
 template <int OT>
 constexpr size_t fast_lds_bytes() {
   return (size_t)kFastMT * 2 * 64 * 16 + (size_t)kFastKP * OT * 2 * 64 * 16 + 4 * 256 * sizeof(float) + 3 * 32 * sizeof(float) + 64 +
-         (size_t)kPhiN * 16 + 32 * sizeof(float) + (size_t)kFastKP * OT * 64 * 16;
+         (size_t)kPhiN * 16 + 32 * sizeof(float) + (size_t)kFastKP * OT * 64 * 16 + 2 * 256 * sizeof(float);
 }
 
 template <int OT>      // 16-row output tiles: 2 (cout = 30) or 1 (cout = 15)
@@ -493,11 +507,13 @@ __global__ __launch_bounds__(512, TT_FULLPW_MINWAVES) void full_pw_fast_kernel(F
   uint4 *w2f = w1f + MT * 2 * 64;                               // [KP][OT][plane][lane]: layer-2 A fragments
   float *s1f = (float *)(w2f + KP * OT * 2 * 64);               // [256] BatchNorm1 scale / layer-1 prescale
   float *t1f = s1f + 256, *zmx = t1f + 256, *egm = zmx + 256;   // [256] each: shift; zmax_m; eg_m
+
   float *s2f = egm + 256, *t2f = s2f + 32, *tau = t2f + 32;     // [32] each (tau: the part of the bound that does not depend on the pixel)
   float *tauk = tau + 32;                                       // [32] bound per unit of the accumulated |w2| x |g|
   float *red = tauk + 32;                                       // [16] reductions
   float4 *phi = (float4 *)(red + 16);                           // [512] GELU table
   uint4 *w2a = (uint4 *)(phi + kPhiN);                          // [KP][OT][lane]: |w2|, high halves, layer-2 fragment order
+  float *s1n = (float *)(w2a + KP * OT * 64), *t1n = s1n + 256; // [256] each: scale, shift + magic number of the node computation (gelu_node_fast)
   __shared__ double erf_tab[kErfN * kErfC];
   erf_table_to_lds(erf_tab);
   const int g = blockIdx.x, cout = a.cout;
@@ -558,11 +574,13 @@ __global__ __launch_bounds__(512, TT_FULLPW_MINWAVES) void full_pw_fast_kernel(F
         const double ez = fabs(sc) * A * (4.76837158203125e-7 + 16.0 * 5.9604644775390625e-8) + 3.0 * 5.9604644775390625e-8 * zmax;
         s1f[m] = (float)(sc * (double)ACT_PRESCALE / (double)ws1);
         t1f[m] = (float)(sh * (double)ACT_PRESCALE);
+        s1n[m] = (float)(sc * 32.0 / (double)ws1);
+        t1n[m] = (float)(sh * 32.0 + (double)kNodeMagic);
         zmx[m] = (float)zmax;
         egm[m] = (float)(1.13 * ez + 4e-7 * (zmax + 0.1));
         if (!(zmax * (double)ACT_PRESCALE < 65000.0)) red[15] = 1.0f;     // |gelu(z)| <= |z| <= zmax: only then can a split overflow
       } else {
-        s1f[m] = 0.f; t1f[m] = 0.f; zmx[m] = 0.f; egm[m] = 0.f;
+        s1f[m] = 0.f; t1f[m] = 0.f; zmx[m] = 0.f; egm[m] = 0.f; s1n[m] = 0.f; t1n[m] = kNodeMagic;
       }
     }
     __syncthreads();
@@ -594,6 +612,8 @@ __global__ __launch_bounds__(512, TT_FULLPW_MINWAVES) void full_pw_fast_kernel(F
   const uint32_t cap = (uint32_t)a.n * (uint32_t)a.H * (uint32_t)a.W;
   bool out_of_range = false;
   const bool check_range = red[15] != 0.f;               // (block-uniform; false for any sane BatchNorm)
+  // gelu_node_fast: byte address of table entry i = phi + 16 i, i = (bits of t) - (bits of the magic number) + 256
+  const uint32_t phi_k = (uint32_t)((uint8_t *)phi - lds_raw) + 16u * (uint32_t)(kPhiN / 2) - (0x4B400000u << 4);
 #ifdef TT_FULLPW_STAMP
   const bool stamping = blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0;
   unsigned long long stamp_t = 10ull * __builtin_amdgcn_s_memrealtime();
@@ -649,6 +669,7 @@ __global__ __launch_bounds__(512, TT_FULLPW_MINWAVES) void full_pw_fast_kernel(F
         if ((kPwSkip & 4) == 0 && mt < MT) {
           const f16x8 wa = __builtin_bit_cast(f16x8, w1f[(mt * 2 + 0) * 64 + lane]), wb = __builtin_bit_cast(f16x8, w1f[(mt * 2 + 1) * 64 + lane]);
           const f32x4 sc = *(const f32x4 *)(s1f + 16 * mt + 4 * lg), sh = *(const f32x4 *)(t1f + 16 * mt + 4 * lg);
+          const f32x4 scn = *(const f32x4 *)(s1n + 16 * mt + 4 * lg), shn = *(const f32x4 *)(t1n + 16 * mt + 4 * lg);
           // All four pixel tiles of the hidden tile at once: eight matrix instructions, then sixteen independent
           // BatchNorm / node computations, sixteen table reads in flight, sixteen evaluations.  (Tile by tile, every
           // step waited for the one before: 150 cycles per value with two waves per SIMD.)
@@ -658,17 +679,17 @@ __global__ __launch_bounds__(512, TT_FULLPW_MINWAVES) void full_pw_fast_kernel(F
 #pragma unroll
           for (int nt = 0; nt < 4; ++nt) d[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa, __builtin_bit_cast(f16x8, xb[nt]), d[nt], 0, 0, 0);
           float zs[16], dz[16];
-          int node[16];
+          uint32_t node[16];                            // LDS byte address of the table entry
 #pragma unroll
           for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
             for (int i = 0; i < 4; ++i) {               // register i = hidden unit 16 mt + 4 (l/16) + i
               zs[4 * nt + i] = fmaf(d[nt][i], sc[i], sh[i]);
-              node[4 * nt + i] = gelu_node<(int)ACT_PRESCALE>(zs[4 * nt + i], dz[4 * nt + i]);
+              node[4 * nt + i] = gelu_node_fast<(int)ACT_PRESCALE>(d[nt][i], scn[i], shn[i], zs[4 * nt + i], dz[4 * nt + i], phi_k);
             }
           float4 cf[16];
 #pragma unroll
-          for (int e = 0; e < 16; ++e) cf[e] = phi[node[e]];
+          for (int e = 0; e < 16; ++e) cf[e] = *(const float4 *)(lds_raw + node[e]);
           float gv[16];
 #pragma unroll
           for (int e = 0; e < 16; ++e) gv[e] = gelu_eval(zs[e], dz[e], cf[e]);
