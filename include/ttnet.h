@@ -140,9 +140,9 @@ int ttnet_forward_u8(ttnet_plan *plan, int lane, const uint8_t *x_nhwc_dev, int6
  * 8-bit fixed point (horizontal pass, then vertical); the output size and crop offsets follow
  * torchvision.transforms.functional (shorter side -> resize, longer side int(resize * long / short);
  * offsets int(round((size - crop) / 2.0))).  Not bound to a plan.  Synchronises `stream` before returning
- * (it frees its scratch).  Parity with Pillow itself is UNPINNED here (Pillow / torchvision are not
- * importable where this is built and tested): the kernels are checked against a numpy restatement of
- * the published algorithm (oracle/pil_resize.py). */
+ * (it frees its scratch).  Byte-identical to Pillow 12.x on the committed fixture tests/golden/ref_resize.npz
+ * (Pillow's own outputs for seeded images of nine geometries); torchvision is not importable where this is
+ * built, so its output-size and crop-offset rules are restated. */
 int ttnet_resize_center_crop_u8(const uint8_t *src_hwc_dev, int64_t n, int h, int w, int resize, int crop,
                                 uint8_t *dst_hwc_dev, void *stream);
 

@@ -364,6 +364,39 @@ def gen_spread(variants=("small", "xsmall", "full")):
         json.dump(out, f, indent=1)
 
 
+def gen_resize():
+    """tests/golden/ref_resize.npz: what PILLOW ITSELF computes for Resize(256) + CenterCrop(224)
+    (utils/preprocess.py:104-105 = torchvision calling ``Image.resize(size[::-1], BILINEAR)`` and cropping).
+    Pillow is importable in the build container (12.x); torchvision is not, so its two integer rules
+    (``_compute_resized_output_size`` and ``center_crop``'s offsets) are restated here and in
+    oracle/pil_resize.py.  Per geometry: SHA-256 of Pillow's crop of two seeded test images
+    (tests/_util.py:resize_test_images) and, for two geometries, the full crop of the first image."""
+    from PIL import Image
+    import PIL
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from _util import RESIZE_GEOMETRIES, resize_test_images
+    from oracle import pil_resize as PR
+    out = {"pillow_version": np.array(PIL.__version__)}
+    for (h, w) in RESIZE_GEOMETRIES:
+        x = resize_test_images(2, h, w, seed=h * 1000 + w)
+        nh, nw = PR.resized_size(h, w, 256)          # torchvision's size rule (restated)
+        crops = []
+        for i in range(2):
+            im = Image.fromarray(x[i])
+            if (nh, nw) != (h, w):
+                im = im.resize((nw, nh), Image.BILINEAR)
+            a = np.asarray(im)
+            top, left = int(round((nh - 224) / 2.0)), int(round((nw - 224) / 2.0))      # torchvision center_crop
+            crops.append(a[top:top + 224, left:left + 224].copy())
+            assert np.array_equal(crops[-1], PR.resize_center_crop(x[i])), (h, w, "oracle/pil_resize.py != Pillow")
+        out[f"sha_{h}x{w}"] = np.array([sha(c) for c in crops])
+        if (h, w) in ((375, 500), (1200, 900)):
+            out[f"crop_{h}x{w}"] = crops[0]
+    np.savez_compressed(os.path.join(GOLD, "ref_resize.npz"), **out)
+    print(f"[resize] Pillow {PIL.__version__}: {len(RESIZE_GEOMETRIES)} geometries x 2 images, "
+          f"oracle/pil_resize.py byte-identical on all")
+
+
 def main(variants):
     os.makedirs(GOLD, exist_ok=True)
     torch.set_num_threads(8)
@@ -488,6 +521,8 @@ if __name__ == "__main__":
         gen_export_golden()
     elif sys.argv[1:] == ["spread"]:
         gen_spread()
+    elif sys.argv[1:] == ["resize"]:
+        gen_resize()
     elif sys.argv[1:2] == ["depth"]:
         for L in [int(a) for a in sys.argv[2:]] or [3, 4]:
             gen_depth_golden(L)
@@ -497,3 +532,4 @@ if __name__ == "__main__":
         for L in (3, 4):
             gen_depth_golden(L)
         gen_spread()
+        gen_resize()

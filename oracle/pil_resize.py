@@ -1,9 +1,13 @@
 """ORACLE (test infrastructure, not product code) -- Resize + CenterCrop of the eval transform.
 
-PARITY UNPINNED: the reference's ``transforms.Resize(256)`` / ``CenterCrop(224)``
-(utils/preprocess.py:104-105) are torchvision calling Pillow; neither library is importable in the
-build container or on the GPU box and the reference holds no fixture for them.  This file restates
-the published algorithms in numpy and is what the HIP kernels (csrc/preproc.hip) are compared with:
+The reference's ``transforms.Resize(256)`` / ``CenterCrop(224)`` (utils/preprocess.py:104-105) are
+torchvision calling Pillow.  PINNED TO PILLOW: Pillow 12.x is importable in the build container;
+``oracle/gen_golden.py resize`` runs ``Image.resize(BILINEAR)`` on seeded images, asserts that this file
+is byte-identical to it on 9 geometries and commits Pillow's outputs as ``tests/golden/ref_resize.npz``;
+``tests/test_pil_resize_oracle.py`` re-checks this file against that fixture (and against Pillow directly
+where it imports), ``tests/test_gpu_preprocess.py`` checks the HIP kernels (csrc/preproc.hip) against the
+fixture.  torchvision is NOT importable here: its two integer rules (output size, crop offsets) are restated
+from its published source and are the only unpinned part.  This file restates the algorithms in numpy:
 
   * Pillow 9/10 ``src/libImaging/Resample.c``: ``precompute_coeffs`` (support = filter support x
     max(scale, 1): antialiasing), ``normalize_coeffs_8bpc`` (22-bit fixed point, round half away),

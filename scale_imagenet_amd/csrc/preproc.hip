@@ -10,9 +10,10 @@
 // (integer for integer); the coefficient tables are built on the host in float64 like Pillow's, the
 // two passes run as kernels that compute only what the centre crop keeps.
 //
-// Parity: UNPINNED -- neither Pillow nor torchvision is importable in the build container or on the
-// GPU box, so the kernels are checked against oracle/pil_resize.py, a numpy restatement of the same
-// published algorithm, not against Pillow itself.
+// Parity: pinned to Pillow 12.x -- tests/golden/ref_resize.npz holds Pillow's own outputs for seeded images of
+// nine geometries (oracle/gen_golden.py resize, run in the build container where Pillow imports) and
+// tests/test_gpu_preprocess.py compares these kernels with it byte for byte.  torchvision is not importable:
+// its output-size and crop-offset rules are restated.
 
 #include <math.h>
 

@@ -49,3 +49,24 @@ def spec_and_state(variant: str):
     from scale_imagenet_amd.synth import synth_state_dict
     spec = VAlexSpec() if variant == "valexnet" else make_spec(variant, **VARIANT_ARGS[variant])
     return spec, synth_state_dict(spec)
+
+
+RESIZE_GEOMETRIES = [(375, 500), (500, 333), (256, 256), (300, 256), (256, 341), (224, 224), (1200, 900), (333, 500),
+                     (480, 640)]
+
+
+def resize_test_images(n: int, h: int, w: int, seed: int) -> np.ndarray:
+    """uint8 [n,h,w,3] test images for the Resize / CenterCrop checks: 8-pixel blocks plus noise (edges and
+    flats).  numpy's PCG64 stream is stable across versions, so oracle/gen_golden.py (which feeds these to
+    Pillow) and the tests regenerate identical inputs."""
+    rng = np.random.default_rng(seed)
+    base = rng.integers(0, 256, size=(n, h // 8 + 2, w // 8 + 2, 3), dtype=np.uint8)
+    img = np.repeat(np.repeat(base, 8, axis=1), 8, axis=2)[:, :h, :w].astype(np.int16)
+    img += rng.integers(-20, 21, size=img.shape, dtype=np.int16)
+    return np.clip(img, 0, 255).astype(np.uint8)
+
+
+@lru_cache(maxsize=None)
+def golden_resize():
+    with np.load(os.path.join(GOLD, "ref_resize.npz")) as z:
+        return {k: z[k] for k in z.files}

@@ -1,35 +1,37 @@
-"""GPU: Resize(256) + CenterCrop(224) on the device against the numpy restatement of
-Pillow's 8-bit bilinear resampling (oracle/pil_resize.py; parity with Pillow itself is unpinned -- it is
-not importable here), and the whole eval transform + forward against the float32 path."""
+"""GPU: Resize(256) + CenterCrop(224) on the device against Pillow's own output (the committed
+fixture tests/golden/ref_resize.npz, written by oracle/gen_golden.py resize from Pillow 12.x) and against the
+numpy restatement of Pillow's 8-bit bilinear resampling (oracle/pil_resize.py, itself pinned to that fixture by
+tests/test_pil_resize_oracle.py); then the whole eval transform + forward against the float32 path."""
 import numpy as np
 import pytest
 import torch
 
-from _util import args_for, spec_and_state
+from _util import RESIZE_GEOMETRIES, args_for, golden_resize, resize_test_images, sha, spec_and_state
 from oracle import pil_resize as PR
 from scale_imagenet_amd import _lib, preprocess, synth, ttnet
 
 pytestmark = pytest.mark.gpu
 
 
-def _images(n, h, w, seed):
-    rng = np.random.default_rng(seed)
-    base = rng.integers(0, 256, size=(n, h // 8 + 2, w // 8 + 2, 3), dtype=np.uint8)        # blocky + noise: edges and flats
-    img = np.repeat(np.repeat(base, 8, axis=1), 8, axis=2)[:, :h, :w].astype(np.int16)
-    img += rng.integers(-20, 21, size=img.shape, dtype=np.int16)
-    return np.clip(img, 0, 255).astype(np.uint8)
+_images = resize_test_images
 
 
-@pytest.mark.parametrize("h,w", [(375, 500), (500, 333), (256, 256), (300, 256), (256, 341), (224, 224), (1200, 900)])
-def test_resize_center_crop_matches_the_pillow_restatement(h, w):
+@pytest.mark.parametrize("h,w", RESIZE_GEOMETRIES)
+def test_resize_center_crop_matches_pillow(h, w):
+    """preproc.hip byte for byte against Pillow's output on the same seeded images (fixture) and against
+    oracle/pil_resize.py."""
     dev = torch.device("cuda", 0)
     x = _images(2, h, w, seed=h * 1000 + w)
+    g = golden_resize()
     if min(PR.resized_size(h, w, 256)) < 224:
         with pytest.raises(_lib.TTNetError):
             preprocess.resize_center_crop_u8(torch.from_numpy(x).to(dev))
         return
     got = preprocess.resize_center_crop_u8(torch.from_numpy(x).to(dev)).cpu().numpy()
     assert got.shape == (2, 224, 224, 3)
+    assert [sha(got[i]) for i in range(2)] == g[f"sha_{h}x{w}"].tolist(), (h, w, "differs from Pillow's output")
+    if f"crop_{h}x{w}" in g:
+        assert np.array_equal(got[0], g[f"crop_{h}x{w}"])
     for i in range(2):
         want = PR.resize_center_crop(x[i])
         assert np.array_equal(got[i], want), (h, w, int(np.abs(got[i].astype(int) - want.astype(int)).max()))

@@ -1,8 +1,36 @@
-"""CPU: properties of the Resize / CenterCrop restatement (oracle/pil_resize.py).  Pillow and torchvision
-are not importable here, so these are the algorithm's own invariants, not a comparison with Pillow."""
+"""CPU: the Resize / CenterCrop restatement (oracle/pil_resize.py) against Pillow's own output -- the committed
+fixture tests/golden/ref_resize.npz (oracle/gen_golden.py resize: Pillow 12.x ``Image.resize(BILINEAR)`` +
+torchvision's crop offsets on seeded images) and, where Pillow is importable, Pillow itself -- plus the
+algorithm's own invariants.  torchvision is not importable in the build container: its size and crop rules
+(two integer formulas) are restated."""
 import numpy as np
+import pytest
 
+from _util import RESIZE_GEOMETRIES, golden_resize, resize_test_images, sha
 from oracle import pil_resize as PR
+
+
+@pytest.mark.parametrize("h,w", RESIZE_GEOMETRIES)
+def test_restatement_matches_the_pillow_fixture(h, w):
+    g = golden_resize()
+    x = resize_test_images(2, h, w, seed=h * 1000 + w)
+    crops = [PR.resize_center_crop(x[i]) for i in range(2)]
+    assert [sha(c) for c in crops] == g[f"sha_{h}x{w}"].tolist()
+    if f"crop_{h}x{w}" in g:
+        assert np.array_equal(crops[0], g[f"crop_{h}x{w}"])
+
+
+@pytest.mark.parametrize("h,w", [(375, 500), (500, 333), (257, 256), (1200, 900), (231, 640), (256, 256)])
+def test_restatement_matches_pillow_directly(h, w):
+    Image = pytest.importorskip("PIL.Image")
+    x = resize_test_images(1, h, w, seed=17 * h + w)[0]
+    nh, nw = PR.resized_size(h, w, 256)
+    im = Image.fromarray(x)
+    if (nh, nw) != (h, w):
+        im = im.resize((nw, nh), Image.BILINEAR)
+    a = np.asarray(im)
+    top, left = int(round((nh - 224) / 2.0)), int(round((nw - 224) / 2.0))
+    assert np.array_equal(PR.resize_center_crop(x), a[top:top + 224, left:left + 224])
 
 
 def test_output_size_and_crop_rules():
