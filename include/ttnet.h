@@ -60,7 +60,21 @@ typedef enum ttnet_variant {
 
 /* The constructor arguments of the reference model (args.nfilter / tfilter / layers,
  * models/TT_general_imagenet_v2_small.py:154-181; main.py:47-50) plus what the reference
- * discovers with a dry run on torch.rand(1,3,224,224) (:199-207): the input size. */
+ * discovers with a dry run on torch.rand(1,3,224,224) (:199-207): the input size.
+ *
+ * Which (variant, p = nfilter * tfilter, layers) the reference constructs and this library builds
+ * (everything else: ttnet_plan_create returns TTNET_E_UNSUPPORTED with the reason in ttnet_last_error):
+ *   TTNET_SMALL    reference: any p for which nn.Conv2d accepts groups = int(C / 16) for C = p, 2p, 4p .. and 4C
+ *                  (:28-76; e.g. every multiple of 16, but also p = 40 with a fan-in of 20), layers 0..4.
+ *                  built: p in {16, 32, 48, 64} (fan-in 16: the truth-table kernels; the stem kernel holds two
+ *                  32-channel M-tiles), layers 0..4.  Not built: p > 64, p % 16 != 0.
+ *   TTNET_XSMALL   reference: any p with p % 4 == 0 ..., layers 0..4.  built: p <= 64 with p % 4 == 0, layers 0..2
+ *                  (the stride-1 first blocks of layers 3 / 4 exist for TTNET_SMALL only).
+ *   TTNET_FULL     reference: p = 60 and the other p for which int(4C / 30) divides 4C (p = 64 does NOT construct,
+ *                  SURVEY 2 #2), layers 0..4.  built: those p <= 64, layers 0..2.
+ *   TTNET_VALEXNET fixed geometry.
+ * image_h = image_w = 224 (32 for TTNET_VALEXNET): the reference's branch-padding rules are keyed by the widths that
+ * 224 x 224 produces (:98-139); other input sizes fall through them in the reference and are refused here. */
 typedef struct ttnet_net_desc {
   int32_t variant;     /* ttnet_variant */
   int32_t nfilter;     /* main.py:47, default 8 */

@@ -61,7 +61,7 @@ CALIB_IMAGES = 64
 CALIB_FIRST = 100000      # calibration images are disjoint from every test batch
 
 
-def import_reference(variant: str, layers: int = None):
+def import_reference(variant: str, layers: int = None, nfilter: int = None, tfilter: int = None):
     for name in ("torchvision", "torchvision.transforms", "torchvision.utils", "torchvision.datasets"):
         sys.modules.setdefault(name, types.ModuleType(name))
     sys.modules["torchvision"].transforms = sys.modules["torchvision.transforms"]
@@ -81,6 +81,8 @@ def import_reference(variant: str, layers: int = None):
         a = dict(VARIANT_ARGS[variant])
         if layers is not None:
             a["layers"] = layers
+        if nfilter is not None:
+            a["nfilter"], a["tfilter"] = nfilter, tfilter
         m = M(Namespace(groups=[1, None, 4, None], **a)).eval()
     return m
 
@@ -287,12 +289,14 @@ def gen_export_golden(n_filters: int = 12):
           f"{sum(1 for v in out['filters'].values() if v['dnf'])} with expressions")
 
 
-def gen_depth_golden(layers: int, n: int = 2):
+def gen_depth_golden(layers: int, n: int = 2, nfilter: int = 8, tfilter: int = 8, out_name: str = None):
     """tests/golden/ref_small_l<layers>.npz: --layers 3 / 4 of TT-small (a stride-1 first block,
     TT_general_imagenet_v2_small.py:178-181, :95-96) on n synthetic images -- the reference's logits
-    and per-stage hashes; also asserts oracle/ttnet_float.py == reference bit for bit."""
-    spec = make_spec("small", 8, 8, layers)
-    m = import_reference("small", layers)
+    and per-stage hashes; also asserts oracle/ttnet_float.py == reference bit for bit.
+    With nfilter x tfilter != 64 (``width``): tests/golden/ref_small_p<p>.npz, another width of the same net
+    (:165-167)."""
+    spec = make_spec("small", nfilter, tfilter, layers)
+    m = import_reference("small", layers, nfilter, tfilter)
     layout = state_dict_layout(spec)
     assert list(m.state_dict().keys()) == list(layout.keys()), "state_dict key order differs"
     st = synth.synth_state_dict(spec, calibrated=False)
@@ -316,10 +320,10 @@ def gen_depth_golden(layers: int, n: int = 2):
     for k in ["features.3"] + [b.name for b in spec.blocks[:-1]]:
         assert torch.equal(taps[k], ref_taps[k]), (layers, k)
         stages[k] = sha(OB.pack_rows(ref_taps[k].numpy().astype(np.uint8)))
-    np.savez_compressed(os.path.join(GOLD, f"ref_small_l{layers}.npz"), logits=y_ref.numpy(), n_images=n,
+    np.savez_compressed(os.path.join(GOLD, out_name or f"ref_small_l{layers}.npz"), logits=y_ref.numpy(), n_images=n,
                         stage_names=np.array(list(stages.keys())), stage_sha=np.array(list(stages.values())),
                         n_keys=len(layout))
-    print(f"[small --layers {layers}] oracle == reference on {n} images; {len(layout)} state keys; "
+    print(f"[small p={nfilter * tfilter} --layers {layers}] oracle == reference on {n} images; {len(layout)} state keys; "
           f"shapes {[tuple(ref_taps[b.name].shape[1:]) for b in spec.blocks]}")
 
 
@@ -523,6 +527,9 @@ if __name__ == "__main__":
         gen_spread()
     elif sys.argv[1:] == ["resize"]:
         gen_resize()
+    elif sys.argv[1:2] == ["width"]:                  # e.g. `width 4 8`: p = 32
+        nf, tf = (int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) >= 4 else (4, 8)
+        gen_depth_golden(1, nfilter=nf, tfilter=tf, out_name=f"ref_small_p{nf * tf}.npz")
     elif sys.argv[1:2] == ["depth"]:
         for L in [int(a) for a in sys.argv[2:]] or [3, 4]:
             gen_depth_golden(L)
@@ -533,3 +540,4 @@ if __name__ == "__main__":
             gen_depth_golden(L)
         gen_spread()
         gen_resize()
+        gen_depth_golden(1, nfilter=4, tfilter=8, out_name="ref_small_p32.npz")

@@ -391,7 +391,7 @@ __global__ __launch_bounds__(512) void full_pw_mfma_kernel(FullPwArgs a) {
 // float64 one -- provided tau really bounds the error.  tau (per output channel, computed by the kernel from
 // the weights it stages): with A_m = sum_c |w1[m][c]|, zmax_m = |s1_m| A_m + |t1_m| (no hidden unit can exceed it),
 //     ez_m = |s1_m| A_m (2^-21 + 16 x 2^-24) + 3 x 2^-24 zmax_m       layer 1: operand split, accumulation, BatchNorm fma
-//     eg_m = 1.13 ez_m + 4e-7 (zmax_m + 0.1)                           GELU: its slope, its own error (below)
+//     eg_m = 1.13 ez_m + 2.4e-6 (zmax_m + 0.1)                         GELU: its slope, its own error (below: gelu_node_fast)
 //     E    = sum_m |w2[o][m]| eg_m + 3.2e-6 sum_m |w2[o][m]| |g_m|     layer 2: both operand splits, the dropped
 //                                                                      low x low product, 32 roundings of the sum
 //     tau  = 2 (|s2_o| E + 2^-22 |t2_o|)                               factor 2: margin
@@ -438,9 +438,14 @@ __device__ inline int gelu_node(float zs, float &dz) {
   return (int)r + kPhiN / 2;
 }
 __device__ inline float gelu_eval(float zs, float dz, const float4 &c) { return zs * fmaf(dz, fmaf(dz, c.z, c.y), c.x); }
-// The node without a round, a convert and an index shift: t = 2^23 x 1.5 + (argument in units of 1/32) holds the
-// nearest node in its low mantissa bits (round to nearest even, like rint), so  t - magic  is the node as a float and
-// (bits of t) << 4 plus a constant is the byte address of its table entry.  d, sc2, sh2: the matrix instruction's
+// The node without a round, a convert and an index shift: t = 2^23 x 1.5 + (argument in units of 1/32) holds a
+// node in its low mantissa bits (round to nearest even, like rint), so  t - magic  is the node as a float and
+// (bits of t) << 4 plus a constant is the byte address of its table entry.  NOT always the nearest node: the shift
+// operand sh2m = 32 shift + magic is itself rounded to an integer (the float32 ulp at 1.5 x 2^23 is 1), so the node is
+// the nearest one of (argument - delta), |delta| <= 1/2 node: |dz| <= 1/32 instead of 1/64, the neglected cubic term
+// 8 x larger.  dz is formed from the node actually taken, so the quadratic is still the expansion around that node;
+// its error is |gelu - gelu_f32| <= 2.4e-6 (|z| + 0.1) (tests/test_full_fast_bounds.py restates this function with
+// the rounded shift: 0.54 of that bound at worst), which is what eg_m of full_pw_fast_kernel uses.  d, sc2, sh2: the matrix instruction's
 // output and BatchNorm scale / shift pre-multiplied by 32 / SCALE (sh2 with the magic number added); zs = the same
 // value in units of 1 / SCALE.  Six vector instructions with gelu_eval's three.
 constexpr float kNodeMagic = 12582912.0f;            // 1.5 x 2^23
@@ -577,7 +582,7 @@ __global__ __launch_bounds__(512, TT_FULLPW_MINWAVES) void full_pw_fast_kernel(F
         s1n[m] = (float)(sc * 32.0 / (double)ws1);
         t1n[m] = (float)(sh * 32.0 + (double)kNodeMagic);
         zmx[m] = (float)zmax;
-        egm[m] = (float)(1.13 * ez + 4e-7 * (zmax + 0.1));
+        egm[m] = (float)(1.13 * ez + 2.4e-6 * (zmax + 0.1));       // (gelu_node_fast: |dz| <= 1/32)
         if (!(zmax * (double)ACT_PRESCALE < 65000.0)) red[15] = 1.0f;     // |gelu(z)| <= |z| <= zmax: only then can a split overflow
       } else {
         s1f[m] = 0.f; t1f[m] = 0.f; zmx[m] = 0.f; egm[m] = 0.f; s1n[m] = 0.f; t1n[m] = kNodeMagic;

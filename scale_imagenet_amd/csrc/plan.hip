@@ -335,8 +335,12 @@ int build_geometry(ttnet_plan *pl) {
   }
   const int p = d.nfilter * d.tfilter;
   pl->p = p;
-  if (p > 64 || (!pl->full && p != 64)) {
-    set_error("p = nfilter*tfilter = %d: the stem kernel covers p <= 64 (and the table variants need p = 64)", p);
+  // The reference constructs any p whose group counts divide its channel counts (TT_general_imagenet_v2_small.py:
+  // 165-167, :28-76); a fan-in of 16 (the truth tables of this build) needs p % 16 == 0 for the small variant and
+  // p % 4 == 0 for x-small.  Built: p <= 64 (two 32-channel M-tiles in the stem kernel); anything else is refused here.
+  if (p > 64 || (!pl->full && p % (pl->xs ? 4 : 16) != 0)) {
+    set_error("p = nfilter*tfilter = %d: built for p <= 64 with p %% %d == 0 (fan-in of the %s truth tables)", p, pl->xs ? 4 : 16,
+              pl->xs ? "x-small" : "small");
     return TTNET_E_UNSUPPORTED;
   }
   std::vector<int> cfg, strides;
@@ -1110,7 +1114,10 @@ bool own_params(hipGraphNode_t node, const int *sizes, int nargs, hipKernelNodeP
   return true;
 }
 
-bool capture_forward(ttnet_plan *pl, const void *x_dev, bool u8, int64_t n, float *logits_dev, ttnet_plan::GraphEntry &e) {
+// *status: what forward_eager returned inside the capture (a caller error -- bad argument, range flag -- is reported to
+// the caller as such and does not turn graph replay off for the plan; only a failure of the capture machinery does)
+bool capture_forward(ttnet_plan *pl, const void *x_dev, bool u8, int64_t n, float *logits_dev, ttnet_plan::GraphEntry &e, int *status) {
+  *status = TTNET_OK;
   if (!pl->cap_stream && hipStreamCreateWithFlags(&pl->cap_stream, hipStreamNonBlocking) != hipSuccess) return false;
   if (hipStreamBeginCapture(pl->cap_stream, hipStreamCaptureModeThreadLocal) != hipSuccess) return false;
   const int r = forward_eager(pl, x_dev, u8, n, logits_dev, pl->cap_stream);
@@ -1119,6 +1126,7 @@ bool capture_forward(ttnet_plan *pl, const void *x_dev, bool u8, int64_t n, floa
   if (r != TTNET_OK || ee != hipSuccess || !g) {
     if (g) (void)hipGraphDestroy(g);
     (void)hipGetLastError();
+    *status = r;
     return false;
   }
   e.graph = g;
@@ -1183,6 +1191,17 @@ int ttnet_plan_set_lanes(ttnet_plan *pl, int lanes) {
 namespace {
 int forward_impl(ttnet_plan *pl, int lane, const void *x_dev, bool u8, int64_t n, float *logits_dev, void *stream) {
   TT_TRY(check_ready(pl, x_dev, n, logits_dev));
+  // The input contract of ttnet.h (16-byte aligned float32, 4-byte aligned uint8: the stem reads it with 16 / 12-byte
+  // buffer loads) is checked HERE, in front of the replay, the capture and the plain path alike: a cached graph
+  // only has its first argument re-pointed and would otherwise take any pointer.
+  if (!pl->va && ((uintptr_t)x_dev & (u8 ? 3u : 15u)) != 0) {
+    set_error("forward: the input must be %d-byte aligned", u8 ? 4 : 16);
+    return TTNET_E_INVALID;
+  }
+  if (((uintptr_t)logits_dev & 3u) != 0) {
+    set_error("forward: the logits buffer must be 4-byte aligned");
+    return TTNET_E_INVALID;
+  }
   if (lane < 0 || lane >= (int)pl->lanes.size()) {
     set_error("forward: lane %d but the plan has %d (ttnet_plan_set_lanes)", lane, (int)pl->lanes.size());
     return TTNET_E_INVALID;
@@ -1203,8 +1222,13 @@ int forward_impl(ttnet_plan *pl, int lane, const void *x_dev, bool u8, int64_t n
   if (it == L.graphs.end()) {
     if (++L.eager_calls[key] <= 2) return forward_eager(pl, x_dev, u8, n, logits_dev, s);   // warm: attributes, lazy module load
     ttnet_plan::GraphEntry e;
-    if (!capture_forward(pl, x_dev, u8, n, logits_dev, e)) {
+    int cap_status = TTNET_OK;
+    if (!capture_forward(pl, x_dev, u8, n, logits_dev, e, &cap_status)) {
       drop_graph(e);
+      if (cap_status != TTNET_OK) {          // the forward itself refused the call: the caller's error, graphs stay on
+        --L.eager_calls[key];
+        return cap_status;
+      }
       graphs_off(pl, "capture or instantiation of the forward failed");   // stay on plain launches
       return forward_eager(pl, x_dev, u8, n, logits_dev, s);
     }

@@ -112,5 +112,10 @@ def evaluate(model: torch.nn.Module, batches: Iterable[Tuple[torch.Tensor, torch
     for p in pending:
         retire(p, done)
         done += 1
+    # the range flag of the split operands is reported on the next call of a plan: without this, an overflow in the
+    # last (or only) batch would end in silently invalid metrics
+    inner = getattr(model, "module", model)              # (nn.DataParallel wrapper, main.py:192)
+    if hasattr(inner, "check_range"):
+        inner.check_range()
     print("Acc..", top1_m.avg, top5_m.avg)
     return EvalResult(loss_m.avg, top1_m.avg, top5_m.avg, loss_m.count)

@@ -17,6 +17,7 @@ training mode or a missing library raise.
 from __future__ import annotations
 
 import ctypes as C
+import threading
 from collections import OrderedDict
 from typing import Dict, Optional
 
@@ -182,6 +183,7 @@ class _TTNetBase(nn.Module):
             if isinstance(mod, (nn.BatchNorm2d, nn.BatchNorm1d)):
                 mod.num_batches_tracked.fill_(1)
         self._plans: Dict[int, _Plan] = {}
+        self.__dict__["_plans_lock"] = threading.Lock()
         layout = state_dict_layout(spec)
         mine = self.state_dict()
         assert list(mine.keys()) == list(layout.keys()), "state_dict layout drifted from spec"
@@ -208,6 +210,7 @@ class _TTNetBase(nn.Module):
             if isinstance(mod, (nn.BatchNorm2d, nn.BatchNorm1d)):
                 mod.num_batches_tracked.fill_(1)
         self._plans = {}
+        self.__dict__["_plans_lock"] = threading.Lock()
         assert list(self.state_dict().keys()) == list(valexnet_layout(spec).keys()), "state_dict layout drifted"
 
     # -- plan management ------------------------------------------------------------------
@@ -218,6 +221,9 @@ class _TTNetBase(nn.Module):
         are seen through the addresses and version counters, and the list itself is rebuilt by
         ``_apply`` / ``load_state_dict`` / ``refresh_state()`` (call the latter after assigning a
         new Parameter object to a sub-module by hand)."""
+        src = self.__dict__.get("_sig_source")
+        if src is not None:                  # a DataParallel replica: see _replicate_for_data_parallel
+            return src._state_signature()
         ts = self.__dict__.get("_sig_tensors")
         if ts is None:
             ts = list(self.state_dict().values())
@@ -233,22 +239,50 @@ class _TTNetBase(nn.Module):
         self.__dict__["_sig_tensors"] = None
         return out
 
+    def __getstate__(self):
+        """copy.deepcopy / pickling: plans (device handles), their lock and the signature cache stay behind."""
+        d = dict(self.__dict__)
+        d["_plans"] = {}
+        for k in ("_plans_lock", "_sig_tensors", "_sig_source"):
+            d.pop(k, None)
+        return d
+
+    def __setstate__(self, state):
+        super().__setstate__(state)
+        self.__dict__["_plans_lock"] = threading.Lock()
+        self.__dict__["_sig_tensors"] = None
+
+    def _replicate_for_data_parallel(self):
+        """``nn.DataParallel`` over several devices (main.py:192 wraps over all visible GPUs): ``replicate`` makes a
+        shallow copy of the module per device and per forward, whose parameters are fresh broadcast copies.  A
+        replica therefore (1) shares this module's per-device plan cache -- one plan per device, kept across
+        forwards, creation and reload serialised by a lock shared with the original (``parallel_apply`` runs the
+        replicas on threads) -- and (2) takes its state signature from the ORIGINAL's tensors: its own copies are
+        new tensors on every forward, so their addresses say nothing, while the original's (address, version)
+        pairs change exactly when the weights do.  A replica's plan is then (re)loaded from the replica's own,
+        device-local state_dict only when the weights changed: truth tables are not rebuilt per forward (10.5 ms)."""
+        replica = super()._replicate_for_data_parallel()
+        replica.__dict__["_sig_source"] = self.__dict__.get("_sig_source") or self
+        replica.__dict__["_sig_tensors"] = None
+        return replica
+
     def _plan_for(self, device: torch.device, n: int) -> _Plan:
         idx = device.index if device.index is not None else torch.cuda.current_device()
-        plan = self._plans.get(idx)
-        if plan is not None and n > plan.max_batch:
-            plan.close()
-            plan = None
-        if plan is None:
-            plan = _Plan(self.spec, self.args, idx, max(n, self.DEFAULT_MAX_BATCH))
-            if self.__dict__.get("_lanes", 1) > 1:
-                plan.set_lanes(self._lanes)
-            self._apply_input_norm(plan)
-            self._plans[idx] = plan
-        sig = self._state_signature()
-        if plan.signature != sig:
-            plan.load(self.state_dict(), torch.cuda.current_stream(device).cuda_stream)
-            plan.signature = sig
+        with self.__dict__["_plans_lock"]:
+            plan = self._plans.get(idx)
+            if plan is not None and n > plan.max_batch:
+                plan.close()
+                plan = None
+            if plan is None:
+                plan = _Plan(self.spec, self.args, idx, max(n, self.DEFAULT_MAX_BATCH))
+                if self.__dict__.get("_lanes", 1) > 1:
+                    plan.set_lanes(self._lanes)
+                self._apply_input_norm(plan)
+                self._plans[idx] = plan
+            sig = self._state_signature()
+            if plan.signature != sig:
+                plan.load(self.state_dict(), torch.cuda.current_stream(device).cuda_stream)
+                plan.signature = sig
         return plan
 
     def set_lanes(self, lanes: int):
@@ -267,7 +301,9 @@ class _TTNetBase(nn.Module):
     # -- the hot path ------------------------------------------------------------------------
     def forward(self, x: torch.Tensor, lane: int = 0) -> torch.Tensor:
         """``self.features(x)`` of the reference (netbin.py:703-708), eval mode.  ``lane`` picks
-        the activation workspace (``set_lanes``) when several batches are kept in flight."""
+        the activation workspace (``set_lanes``) when several batches are kept in flight.
+        A value outside the range of the split operands makes the NEXT call raise (sticky flag): after the last
+        batch of a loop, synchronise and call ``check_range()`` (``evaluate.evaluate`` does)."""
         if self.training:
             raise RuntimeError("the HIP path implements eval-mode inference only: call model.eval() "
                                "(main.py:251); training is out of scope")
@@ -339,6 +375,16 @@ class _TTNetBase(nn.Module):
         _lib.check(plan.lib.ttnet_forward_from_stem_bits(plan.handle, C.c_void_p(rows.data_ptr()), n,
                                                          C.c_void_p(out.data_ptr()), C.c_void_p(stream)))
         return out
+
+    def check_range(self):
+        """Raise if a forward since the last check left the range of the fp16 x 2 split operands (|activation| >= 4094:
+        include/ttnet.h, TTNET_E_RANGE).  The kernels raise a sticky flag; the C ABI reports it on the NEXT call of the
+        plan, so a loop that only calls ``forward`` would miss an overflow in its last batch: call this after the
+        synchronisation that ends the loop (``evaluate`` does).  Synchronises the device."""
+        for plan in self._plans.values():
+            if plan.query("range_overflow"):
+                raise RuntimeError("ttnet: an activation left the range of the split operands (|value| >= 4094); "
+                                   "the logits of that batch are invalid (TTNET_E_RANGE)")
 
     def _any_plan(self) -> _Plan:
         if not self._plans:
