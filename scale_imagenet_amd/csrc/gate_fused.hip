@@ -194,7 +194,7 @@ __global__ __launch_bounds__(kFT) void gate_block_kernel(FusedArgs a) {
   int st, sl;
   {
     const int b = blockIdx.x, x = b & 7, k = b >> 3;
-    if (P >= 8) {
+    if (P >= 8 && P % 8 == 0) {                          // (p = 64: 8, 16, 32 strand pairs; other widths take the plain order)
       const int m = P / 8, pair = x + 8 * (k % m), kk = k / m;
       st = 2 * pair + (kk & 1);
       sl = kk >> 1;
