@@ -43,14 +43,20 @@ constexpr int NP = SPLIT_PLANES;
 #endif
 constexpr int kLin1Skip = TT_LIN1_SKIP;
 
-constexpr int G_BM = 256, G_BN = 128;                 // workgroup tile: 8 x 4 MFMA tiles of 32x32
+#ifndef TT_LIN1_BM
+#define TT_LIN1_BM 128
+#endif
+#ifndef TT_LIN1_WGS
+#define TT_LIN1_WGS 256
+#endif
+constexpr int G_BM = TT_LIN1_BM, G_BN = 128;          // workgroup tile: (4 | 8) x 4 MFMA tiles of 32x32
 constexpr int G_MT = G_BM / 32, G_NT = G_BN / 32;
 constexpr int G_KS = 1;                               // k-steps (of 16) per LDS stage
 constexpr int G_CHUNK = 1024;                         // one fragment block: 64 lanes x 16 B
 constexpr int G_STAGE = (G_MT + G_NT) * G_KS * NP * G_CHUNK;  // 24 KiB
 constexpr int G_STAGES = 4;                           // LDS ring: 3 stages in flight behind the one being read (measured: 6 stages, or 2 k-steps
                                                       // per stage, change nothing: the kernel is bound by moving its 768 KiB per workgroup)
-constexpr int G_WAVES = 8;                            // two waves per SIMD: one wave's LDS reads / waits hide behind the other's MFMAs
+constexpr int G_WAVES = G_BM / 32;                     // one M-tile per wave; two workgroups per CU at G_BM = 128: one's ramp, waits and slab stores hide behind the other's MFMAs
 constexpr int G_CHUNKS = (G_MT + G_NT) * G_KS * NP;   // 24 fragment blocks per stage
 constexpr int G_LOADS = (G_CHUNKS + G_WAVES - 1) / G_WAVES;   // direct-to-LDS loads per wave and stage (3; any
                                                       // surplus slots load into a scratch block so every wave counts the same)
@@ -73,10 +79,10 @@ __global__ __launch_bounds__(64 * G_WAVES) void gemm_f16x2_kernel(const uint8_t 
     const int round = b / (lanes8 * n_tiles), rem = b % (lanes8 * n_tiles);
     int grp = round * lanes8 + rem % lanes8;
     ntile = rem / lanes8;
-    if (grp >= groups) {                                          // ragged last round: plain order
-      const int base = (groups / lanes8) * lanes8 * n_tiles, o = b - base, left = groups - (groups / lanes8) * lanes8;
-      grp = (groups / lanes8) * lanes8 + o % left;
-      ntile = o / left;
+    if (round == groups / lanes8) {                               // ragged last round (fewer than 8 groups left): EVERY block of it
+      const int left = groups - round * lanes8;                   // takes the narrower interleave (round 2 remapped only the
+      grp = round * lanes8 + rem % left;                          // blocks whose group index overflowed: with 4 of 8 groups left,
+      ntile = rem / left;                                         // (group, N-tile) pairs were then computed twice and others never)
     }
     mtile = grp / splits;
     slice = grp % splits;
@@ -321,10 +327,13 @@ __global__ void permute_lin1_kernel(const float *__restrict__ w1, float *__restr
 }  // namespace
 
 int gemm_f16x2_splits(int M, int N, int KS) {
-  // the most K-slices (a divisor of the k-step count, slices of at least 8 k-steps) that still give
-  // at most one workgroup per CU
+  // the most K-slices (a divisor of the k-step count, slices of at least 8 k-steps) that still give at most one
+  // workgroup per CU -- but never fewer than 8 where the shape allows it: a slice is one float32 accumulation chain per
+  // output, and chains longer than 2048 terms cost accuracy (batch 600: 4 slices of 4096 put the logits 1.03e-5 from
+  // the 16-slice result of batch 256); the slices themselves are summed in float64 by head_mid_kernel
   const int tiles = ((M + G_BM - 1) / G_BM) * ((N + G_BN - 1) / G_BN);
-  for (int s = std::min(std::min(256 / std::max(1, tiles), KS / 8), 128); s > 1; --s)   // (<= 128: the reduce pass reads every slab)
+  const int want = std::max(TT_LIN1_WGS / std::max(1, tiles), 8);
+  for (int s = std::min(std::min(want, KS / 8), 128); s > 1; --s)   // (<= 128: the reduce pass reads every slab)
     if (KS % s == 0) return s;
   return 1;
 }

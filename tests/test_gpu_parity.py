@@ -550,7 +550,9 @@ def test_errors_are_loud(small_model, dev):
     lib.ttnet_plan_destroy(h)
     desc = _lib.NetDesc(2, 8, 8, 1, 224, 224, 4, 0)      # full at p = 64: in_channels not divisible by groups
     assert lib.ttnet_plan_create(C.byref(desc), 0, C.byref(h)) == -1
-    desc = _lib.NetDesc(0, 8, 6, 1, 224, 224, 4, 0)      # small at p = 48: the table variants need p = 64
+    desc = _lib.NetDesc(0, 8, 5, 1, 224, 224, 4, 0)      # small at p = 40: a fan-in of 20, no truth-table kernel (p = 16..64 in steps of 16 are built)
+    assert lib.ttnet_plan_create(C.byref(desc), 0, C.byref(h)) == -4 and b"p % 16" in lib.ttnet_last_error()
+    desc = _lib.NetDesc(0, 12, 8, 1, 224, 224, 4, 0)     # small at p = 96: beyond the stem kernel's two M-tiles
     assert lib.ttnet_plan_create(C.byref(desc), 0, C.byref(h)) == -4
     with pytest.raises(RuntimeError):
         model(torch.zeros((1, 3, 32, 32), device=dev))
