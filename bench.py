@@ -147,7 +147,7 @@ def measured_traffic(variant: str, batch: int):
     import glob
     pats = [f"*traffic_{variant}_b{batch}.json"] + ([f"*traffic_b{batch}.json"] if variant == "small" else [])
     files = sorted(f for p in pats for f in glob.glob(os.path.join(ROOT, "profiles", p)))
-    files = [f for f in files if os.path.basename(f).startswith("r02")] or files
+    files = sorted(files, key=os.path.basename)          # names start with the round tag (r01a .. r03e): the last is the latest
     if not files:
         return {}, None
     with open(files[-1]) as f:
@@ -248,13 +248,42 @@ def is_lut_kernel(name: str) -> bool:
     return name.startswith(("gate_stage1", "gate_pf", "gate_block"))
 
 
+GATE_LOOKUPS_PER_IMAGE = 241_544      # table lookups of the 11 binarised Block_TTs of TT-small
+VALU_LANES_PER_CLK, VALU_CLK_HZ = 256 * 4 * 32, 2.4e9      # MI355X_MICROARCH.md: 256 CUs x 4 SIMD-32 (a wave64 instruction takes 2 cycles)
+
+
+def measured_counters():
+    """SQ counters per launch of the gate kernels from the committed rocprofv3 --pmc pass (profiles/*_counters_small_b256.json,
+    tools/collect_counters.sh): bench.py cannot run the profiler on itself."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_counters_small_b256.json")), key=os.path.basename)
+    if not files:
+        return None, None
+    with open(files[-1]) as f:
+        return json.load(f).get("kernels", {}), os.path.basename(files[-1])
+
+
 def gate_path_record(avg_ms, batch):
     gate_ms = sum(ms for k, ms in avg_ms.items() if is_lut_kernel(k)) or 1e-9
     gate_bytes = GATE_BYTES_PER_IMAGE * batch + GATE_TABLE_BYTES
-    return {"kernel": "gate_path (all binarised LUT launches)", "batch": batch, "ms": round(gate_ms, 5), "bound": "hbm",
-            "achieved": round(gate_bytes / (gate_ms * 1e-3) / 1e9, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(gate_bytes / (gate_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "traffic": None,
-            "launches": sum(1 for k in avg_ms if is_lut_kernel(k))}
+    rec = {"kernel": "gate_path (all binarised LUT launches)", "batch": batch, "ms": round(gate_ms, 5), "bound": "hbm",
+           "achieved": round(gate_bytes / (gate_ms * 1e-3) / 1e9, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+           "frac": round(gate_bytes / (gate_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "traffic": None,
+           "launches": sum(1 for k in avg_ms if is_lut_kernel(k))}
+    # the second, honest bound of a 16-bit-index table path: vector lane-operations.  Floor: 2 per lookup (form the index,
+    # extract the bit / byte) at 32,768 lanes per clock; measured: SQ_INSTS_VALU x 64 lanes of the committed counter pass
+    lookups = GATE_LOOKUPS_PER_IMAGE * batch
+    floor_ms = 2.0 * lookups / (VALU_LANES_PER_CLK * VALU_CLK_HZ) * 1e3
+    rec["valu_bound"] = {"lookups": lookups, "floor_lane_ops_per_lookup": 2, "floor_ms": round(floor_ms, 5),
+                         "frac_of_floor": round(floor_ms / gate_ms, 5)}
+    ctr, src = measured_counters()
+    if ctr and batch == 256:
+        insts = sum(v.get("SQ_INSTS_VALU", 0.0) for k, v in ctr.items() if k.startswith("gate_block"))
+        if insts:
+            rec["valu_bound"].update({"measured_lane_ops_per_lookup": round(insts * 64.0 / lookups, 2),
+                                      "measured_valu_issue_ms_at_2_cycles": round(insts / 1024.0 * 2.0 / VALU_CLK_HZ * 1e3, 5),
+                                      "counters_source": src})
+    return rec
 
 
 def main():

@@ -2,9 +2,10 @@
 usage: python tools/make_counters_profile.py <out.json> <pmc_dir> [<pmc_dir> ...]
 
 Per kernel and launch (mean over the launches of the pass): the raw SQ counters, summed over the chip by
-rocprofv3, plus derived figures: VALU instructions per wave (SQ_INSTS_VALU / SQ_WAVES), MFMA busy share
-(SQ_VALU_MFMA_BUSY_CYCLES / SQ_BUSY_CYCLES -- both summed over the chip's units, see MI355X_MICROARCH.md
-"rocprofv3 PMC slots": SQ_*_CYCLES count quad-cycles, SQ_VALU_MFMA_BUSY_CYCLES cycles)."""
+rocprofv3, plus derived figures: instructions per wave (SQ_INSTS_* / SQ_WAVES), matrix-pipe busy cycles and VALU
+wave-instructions per SIMD (the chip has 1,024 SIMDs; SQ_VALU_MFMA_BUSY_CYCLES counts shader cycles, the other
+SQ_*_CYCLES quad-cycles: MI355X_MICROARCH.md "rocprofv3 PMC slots").  Utilisation = per-SIMD busy cycles / (the
+kernel's duration in profiles/<tag>_kernel_stats_small.csv x the clock the chip holds, 1.5 - 2.1 GHz)."""
 import csv, glob, json, os, sys, collections
 
 LABELS = [("stem_pc_kernel", "stem"), ("gate_last", "gate_last"), ("gemm_f16x2_kernel", "head.lin1"),
@@ -30,8 +31,11 @@ for name, cs in acc.items():
         for k in ("SQ_INSTS_VALU", "SQ_INSTS_LDS", "SQ_INSTS_MFMA", "SQ_INSTS_SALU"):
             if k in c:
                 e[k.replace("SQ_INSTS_", "").lower() + "_per_wave"] = round(c[k] / c["SQ_WAVES"], 1)
-    if c.get("SQ_BUSY_CYCLES") and "SQ_VALU_MFMA_BUSY_CYCLES" in c:
-        e["mfma_busy_over_sq_busy"] = round(c["SQ_VALU_MFMA_BUSY_CYCLES"] / c["SQ_BUSY_CYCLES"], 4)
+    if "SQ_VALU_MFMA_BUSY_CYCLES" in c:
+        # summed over the chip's 1,024 SIMDs, in shader cycles: divide by (kernel time x clock) for the matrix-pipe utilisation
+        e["mfma_busy_cycles_per_simd"] = round(c["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024.0, 1)
+    if "SQ_INSTS_VALU" in c:
+        e["valu_wave_instructions_per_simd"] = round(c["SQ_INSTS_VALU"] / 1024.0, 1)
     e["kernel_name"] = name[:120]
     out["kernels"][label] = e
 json.dump(out, open(sys.argv[1], "w"), indent=1)
