@@ -56,7 +56,12 @@ constexpr int G_CHUNK = 1024;                         // one fragment block: 64 
 constexpr int G_STAGE = (G_MT + G_NT) * G_KS * NP * G_CHUNK;  // 24 KiB
 constexpr int G_STAGES = 4;                           // LDS ring: 3 stages in flight behind the one being read (measured: 6 stages, or 2 k-steps
                                                       // per stage, change nothing: the kernel is bound by moving its 768 KiB per workgroup)
-constexpr int G_WAVES = G_BM / 32;                     // one M-tile per wave; two workgroups per CU at G_BM = 128: one's ramp, waits and slab stores hide behind the other's MFMAs
+#ifndef TT_LIN1_WAVES
+#define TT_LIN1_WAVES (TT_LIN1_BM / 32)
+#endif
+constexpr int G_WAVES = TT_LIN1_WAVES;                 // wave w: M-tile w % G_MT, N-tiles (w / G_MT) * NPW .. + NPW - 1
+constexpr int G_WN = G_WAVES / G_MT, NPW = G_NT / G_WN;
+static_assert(G_WAVES % G_MT == 0 && G_NT % G_WN == 0, "waves tile the workgroup's output");
 constexpr int G_CHUNKS = (G_MT + G_NT) * G_KS * NP;   // 24 fragment blocks per stage
 constexpr int G_LOADS = (G_CHUNKS + G_WAVES - 1) / G_WAVES;   // direct-to-LDS loads per wave and stage (3; any
                                                       // surplus slots load into a scratch block so every wave counts the same)
@@ -120,12 +125,13 @@ __global__ __launch_bounds__(64 * G_WAVES) void gemm_f16x2_kernel(const uint8_t 
     }
   };
 
-  constexpr int MPW = G_MT / G_WAVES;                   // M-tiles per wave (1)
-  f32x16 acc[MPW][G_NT];
+  constexpr int MPW = 1;                                // M-tiles per wave
+  const int wm = wave % G_MT, wn = wave / G_MT;
+  f32x16 acc[MPW][NPW];
 #pragma unroll
   for (int i = 0; i < MPW; ++i)
 #pragma unroll
-    for (int j = 0; j < G_NT; ++j)
+    for (int j = 0; j < NPW; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
@@ -148,32 +154,32 @@ __global__ __launch_bounds__(64 * G_WAVES) void gemm_f16x2_kernel(const uint8_t 
     const uint8_t *st = lds + (it % G_STAGES) * G_STAGE;
 #pragma unroll
     for (int kk = 0; kk < G_KS; ++kk) {
-      f16x8 a[MPW][NP], b[G_NT][NP];
+      f16x8 a[MPW][NP], b[NPW][NP];
 #pragma unroll
       for (int i = 0; i < MPW; ++i)
 #pragma unroll
         for (int pl = 0; pl < NP; ++pl)
-          a[i][pl] = *(const f16x8 *)(st + ((((MPW * wave + i) * G_KS + kk) * NP + pl) * G_CHUNK) + lane * 16);
+          a[i][pl] = *(const f16x8 *)(st + ((((wm + i) * G_KS + kk) * NP + pl) * G_CHUNK) + lane * 16);
 #pragma unroll
-      for (int j = 0; j < G_NT; ++j)
+      for (int j = 0; j < NPW; ++j)
 #pragma unroll
         for (int pl = 0; pl < NP; ++pl)
-          b[j][pl] = *(const f16x8 *)(st + ((G_MT * G_KS * NP + (j * G_KS + kk) * NP + pl) * G_CHUNK) + lane * 16);
+          b[j][pl] = *(const f16x8 *)(st + ((G_MT * G_KS * NP + ((wn * NPW + j) * G_KS + kk) * NP + pl) * G_CHUNK) + lane * 16);
       // the three products of a tile go to the same accumulator: issue them tile-interleaved, so that
       // consecutive MFMAs are independent (same per-accumulator order: low terms first)
       if constexpr (kLin1Skip & 4) {
 #pragma unroll
-        for (int j = 0; j < G_NT; ++j) acc[0][j][0] += (float)a[0][0][0] + (float)b[j][0][0];      // keep the fragment reads alive
+        for (int j = 0; j < NPW; ++j) acc[0][j][0] += (float)a[0][0][0] + (float)b[j][0][0];      // keep the fragment reads alive
         continue;
       }
 #pragma unroll
       for (int i = 0; i < MPW; ++i) {
 #pragma unroll
-        for (int j = 0; j < G_NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][1], b[j][0], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < NPW; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][1], b[j][0], acc[i][j], 0, 0, 0);
 #pragma unroll
-        for (int j = 0; j < G_NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][0], b[j][1], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < NPW; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][0], b[j][1], acc[i][j], 0, 0, 0);
 #pragma unroll
-        for (int j = 0; j < G_NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][0], b[j][0], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < NPW; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][0], b[j][0], acc[i][j], 0, 0, 0);
       }
     }
   }
@@ -186,8 +192,8 @@ __global__ __launch_bounds__(64 * G_WAVES) void gemm_f16x2_kernel(const uint8_t 
 #pragma unroll
   for (int i = 0; i < MPW; ++i)
 #pragma unroll
-    for (int j = 0; j < G_NT; ++j) {
-      float4 *tile = dst + ((size_t)(mt0 + MPW * wave + i) * (n_tiles * G_NT) + nt0 + j) * 256 + lane;
+    for (int j = 0; j < NPW; ++j) {
+      float4 *tile = dst + ((size_t)(mt0 + wm + i) * (n_tiles * G_NT) + nt0 + wn * NPW + j) * 256 + lane;
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         if ((kLin1Skip & 8) && g) continue;
