@@ -336,11 +336,11 @@ int build_geometry(ttnet_plan *pl) {
   const int p = d.nfilter * d.tfilter;
   pl->p = p;
   // The reference constructs any p whose group counts divide its channel counts (TT_general_imagenet_v2_small.py:
-  // 165-167, :28-76); a fan-in of 16 (the truth tables of this build) needs p % 16 == 0 for the small variant and
-  // p % 4 == 0 for x-small.  Built: p <= 64 (two 32-channel M-tiles in the stem kernel); anything else is refused here.
-  if (p > 64 || (!pl->full && p % (pl->xs ? 4 : 16) != 0)) {
-    set_error("p = nfilter*tfilter = %d: built for p <= 64 with p %% %d == 0 (fan-in of the %s truth tables)", p, pl->xs ? 4 : 16,
-              pl->xs ? "x-small" : "small");
+  // 165-167, :28-76); a fan-in of 16 (the truth tables of the small variant) needs p % 16 == 0, and the depthwise
+  // tables of both table variants are striped by 16 channels.  Built: p in {16, 32, 48, 64} (two 32-channel M-tiles in
+  // the stem kernel); anything else is refused here.
+  if (p > 64 || (!pl->full && p % 16 != 0)) {
+    set_error("p = nfilter*tfilter = %d: built for p <= 64 with p %% 16 == 0 (fan-in 16 / tables striped by 16 channels)", p);
     return TTNET_E_UNSUPPORTED;
   }
   std::vector<int> cfg, strides;
@@ -1057,7 +1057,7 @@ int forward_eager(ttnet_plan *pl, const void *x_dev, bool u8, int64_t n, float *
     return run_va_tail(pl, (int)n, logits_dev, s);
   }
   TT_TIMED(pl, "stem", s,
-           launch_stem(x_dev, u8, pl->norm_tab, pl->stem_wt, pl->stem_init, pl->x_rp[0], (pl->full || pl->fused) ? nullptr : pl->x_cp[0], (int)n,
+           launch_stem(x_dev, u8, pl->norm_tab, pl->stem_wt, pl->stem_init, pl->x_rp[0], (pl->full || pl->fused || pl->xs) ? nullptr : pl->x_cp[0], (int)n,
                        pl->p, pl->range_dev, s));
   return run_from_blocks(pl, (int)n, logits_dev, s);
 }

@@ -551,7 +551,7 @@ def test_errors_are_loud(small_model, dev):
     desc = _lib.NetDesc(2, 8, 8, 1, 224, 224, 4, 0)      # full at p = 64: in_channels not divisible by groups
     assert lib.ttnet_plan_create(C.byref(desc), 0, C.byref(h)) == -1
     desc = _lib.NetDesc(0, 8, 5, 1, 224, 224, 4, 0)      # small at p = 40: a fan-in of 20, no truth-table kernel (p = 16..64 in steps of 16 are built)
-    assert lib.ttnet_plan_create(C.byref(desc), 0, C.byref(h)) == -4 and b"p % 16" in lib.ttnet_last_error()
+    assert lib.ttnet_plan_create(C.byref(desc), 0, C.byref(h)) == -4 and b"% 16" in lib.ttnet_last_error()
     desc = _lib.NetDesc(0, 12, 8, 1, 224, 224, 4, 0)     # small at p = 96: beyond the stem kernel's two M-tiles
     assert lib.ttnet_plan_create(C.byref(desc), 0, C.byref(h)) == -4
     with pytest.raises(RuntimeError):
@@ -590,7 +590,7 @@ def test_cabi_comm_single_rank(dev):
     lib.ttnet_comm_destroy(comm)
 
 
-def _check_geometry_against_the_oracle(dev, nfilter, tfilter, layers, golden=None):
+def _check_geometry_against_the_oracle(dev, nfilter, tfilter, layers, golden=None, variant="small"):
     """Three independent checks of a (p, --layers) geometry:
       1. every GPU-built truth table equals the float64 oracle table (OB.build_lut), the float table of the last
          block included, ALL of its groups (in chunks of 8, built on a thread pool);
@@ -601,10 +601,10 @@ def _check_geometry_against_the_oracle(dev, nfilter, tfilter, layers, golden=Non
     from argparse import Namespace
     from concurrent.futures import ThreadPoolExecutor      # (numpy / scipy release the GIL: ~100 s of table building otherwise)
     from scale_imagenet_amd.spec import make_spec
-    tag = f"p={nfilter * tfilter} --layers {layers}"
-    spec = make_spec("small", nfilter, tfilter, layers)
+    tag = f"{variant} p={nfilter * tfilter} --layers {layers}"
+    spec = make_spec(variant, nfilter, tfilter, layers)
     st = synth.synth_state_dict(spec, calibrated=False)
-    m = ttnet.TT_vf_19lv3_imgnet_small(Namespace(nfilter=nfilter, tfilter=tfilter, layers=layers, groups=[1, None, 4, None]))
+    m = CLASSES[variant](Namespace(nfilter=nfilter, tfilter=tfilter, layers=layers, groups=[1, None, 4, None]))
     m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in st.items()}, strict=True)
     m = m.to(dev).eval().reserve(4)
     x = synth.synth_images(3)
@@ -673,6 +673,12 @@ def test_other_widths_against_the_oracle(dev, nfilter, tfilter):
     reference (tests/golden/ref_small_p32.npz)."""
     p = nfilter * tfilter
     _check_geometry_against_the_oracle(dev, nfilter, tfilter, 1, "ref_small_p32.npz" if p == 32 else None)
+
+
+@pytest.mark.parametrize("nfilter,tfilter", [(4, 8), (6, 8)])
+def test_xsmall_other_widths_against_the_oracle(dev, nfilter, tfilter):
+    """The x-small variant (fan-in 4) at p = 32 and p = 48 (TT_general_imagenet_v2_xsmall.py: groups = C / 4)."""
+    _check_geometry_against_the_oracle(dev, nfilter, tfilter, 1, None, "xsmall")
 
 
 def test_unbuilt_widths_are_refused_loudly(dev):
