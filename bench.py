@@ -63,7 +63,8 @@ def parse_args(argv=None):
                          "float32 at batch 256, more than the 256 MiB Infinity Cache, so the stem's input stream really "
                          "comes from HBM; 1 = the same buffer every step)")
     ap.add_argument("--windows", type=int, default=0,
-                    help="timed windows of --steps steps each (0 = 5 when --steps <= 50, else 3); value = the median window")
+                    help="timed windows of --steps steps each (0 = 9 when --steps <= 50 -- a 20-step window is 3 ms, and the clock is still "
+                         "settling during the first ones --, else 3); value = the median window, min / max beside it")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the B = 2048 gate-path pass and the golden-image parity check (profiling runs)")
@@ -360,7 +361,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    n_windows = args.windows if args.windows > 0 else (5 if args.steps <= 50 else 3)
+    n_windows = args.windows if args.windows > 0 else (9 if args.steps <= 50 else 3)
 
     def timed(lanes):
         """W untimed warm-up steps, then n_windows windows of EXACTLY K steps, each bracketed by a barrier +
