@@ -364,6 +364,29 @@ def gen_spread(variants=("small", "xsmall", "full")):
             "threads_1_vs_exact": float(np.abs(y1.numpy() - exact).max()),
         }
         print(f"[spread {variant}]", out["variants"][variant])
+    # the other geometries with a reference capture (ref_small_l3 / _l4 / _p32.npz: uncalibrated heads, |logit| up to ~16):
+    # how far the reference's own float32 logits sit from the float64 head on its own features -- what backs the scaled
+    # allowance of tests/test_gpu_parity.py::_check_geometry_against_the_oracle for these fixtures
+    out["geometries"] = {}
+    for name, (nf, tf, layers) in {"small_l3": (8, 8, 3), "small_l4": (8, 8, 4), "small_p32": (4, 8, 1)}.items():
+        spec = make_spec("small", nf, tf, layers)
+        m = import_reference("small", layers, nf, tf)
+        st = synth.synth_state_dict(spec, calibrated=False)
+        m.load_state_dict(OF.to_torch_state(st), strict=True)
+        fixture = f"ref_small_l{layers}.npz" if nf * tf == 64 else f"ref_small_p{nf * tf}.npz"
+        with np.load(os.path.join(GOLD, fixture)) as z:
+            want, n = z["logits"], int(z["n_images"])
+        x = torch.from_numpy(synth.synth_images(n))
+        flat = {}
+        h = m.features[4 + len(spec.blocks) + 1].register_forward_hook(lambda mod, i, o: flat.__setitem__("f", o.detach().clone()))
+        with torch.no_grad():
+            y = m(x).clone()
+        h.remove()
+        assert np.array_equal(want, y.numpy()), f"{fixture}: the committed logits are this run"
+        exact = OB.head64(flat["f"].numpy(), st, f"features.{4 + len(spec.blocks) + 2}")
+        out["geometries"][name] = {"images": n, "fixture": fixture, "logit_abs_max": float(y.abs().max()),
+                                   "ref_vs_exact": float(np.abs(y.numpy() - exact).max())}
+        print(f"[spread {name}]", out["geometries"][name])
     with open(os.path.join(GOLD, "ref_spread.json"), "w") as f:
         json.dump(out, f, indent=1)
 
