@@ -66,9 +66,10 @@ typedef enum ttnet_variant {
  * (everything else: ttnet_plan_create returns TTNET_E_UNSUPPORTED with the reason in ttnet_last_error):
  *   TTNET_SMALL    reference: any p for which nn.Conv2d accepts groups = int(C / 16) for C = p, 2p, 4p .. and 4C
  *                  (:28-76; e.g. every multiple of 16, but also p = 40 with a fan-in of 20), layers 0..4.
- *                  built: p in {16, 32, 48, 64} (fan-in 16: the truth-table kernels; the stem kernel holds two
- *                  32-channel M-tiles), layers 0..4.  Not built: p > 64, p % 16 != 0.
- *   TTNET_XSMALL   reference: any p with p % 4 == 0 ..., layers 0..4.  built: p in {16, 32, 48, 64} (its depthwise tables are
+ *                  built: p in {16, 32, .., 128} (fan-in 16: the truth-table kernels; the stem kernel holds one, two or
+ *                  four 32-channel M-tiles), layers 0..2; layers 3 / 4 (stride-1 blocks) at p = 64.  Not built: p > 128,
+ *                  p % 16 != 0.
+ *   TTNET_XSMALL   reference: any p with p % 4 == 0 ..., layers 0..4.  built: p in {16, 32, .., 128} (its depthwise tables are
  *                  striped by 16 channels), layers 0..2 (the stride-1 first blocks of layers 3 / 4 exist for TTNET_SMALL only).
  *   TTNET_FULL     reference: p = 60 and the other p for which int(4C / 30) divides 4C (p = 64 does NOT construct,
  *                  SURVEY 2 #2), layers 0..4.  built: those p <= 64, layers 0..2.

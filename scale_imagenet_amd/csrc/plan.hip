@@ -337,10 +337,14 @@ int build_geometry(ttnet_plan *pl) {
   pl->p = p;
   // The reference constructs any p whose group counts divide its channel counts (TT_general_imagenet_v2_small.py:
   // 165-167, :28-76); a fan-in of 16 (the truth tables of the small variant) needs p % 16 == 0, and the depthwise
-  // tables of both table variants are striped by 16 channels.  Built: p in {16, 32, 48, 64} (two 32-channel M-tiles in
-  // the stem kernel); anything else is refused here.
-  if (p > 64 || (!pl->full && p % 16 != 0)) {
-    set_error("p = nfilter*tfilter = %d: built for p <= 64 with p %% 16 == 0 (fan-in 16 / tables striped by 16 channels)", p);
+  // tables of both table variants are striped by 16 channels.  Built: p in {16, 32, .., 128} for the table variants
+  // (one, two or four 32-channel M-tiles in the stem kernel), p <= 64 for the full variant; anything else is refused here.
+  if (p > 128 || (pl->full && p > 64) || (!pl->full && p % 16 != 0)) {
+    set_error("p = nfilter*tfilter = %d: built for p <= 128 with p %% 16 == 0 (fan-in 16 / tables striped by 16 channels; full variant: p <= 64)", p);
+    return TTNET_E_UNSUPPORTED;
+  }
+  if (d.layers >= 3 && p != 64) {
+    set_error("--layers %d at p = %d: the stride-1 blocks (two-launch gate kernels, channel-word layout) are built for p = 64", d.layers, p);
     return TTNET_E_UNSUPPORTED;
   }
   std::vector<int> cfg, strides;

@@ -110,8 +110,7 @@ __device__ unsigned long long g_stem_stamps[256][2][16];
 #define TT_STEM_PROD 4
 #endif
 constexpr int CONS_WAVES = TT_STEM_CONS, PROD_WAVES = TT_STEM_PROD, STEM_THREADS = 64 * (CONS_WAVES + PROD_WAVES);
-static_assert(CONS_WAVES % 2 == 0, "a consumer wave keeps one M-tile: unit u = wave + CONS_WAVES * i has M-tile u & 1 = wave & 1");
-constexpr int UNITS = NT * 2;          // (N-tile, M-tile) pairs of one item: 28
+static_assert(CONS_WAVES % 4 == 0, "a consumer wave keeps one M-tile: unit u = wave + CONS_WAVES * i has M-tile u % MT = wave % MT, MT = 1, 2 or 4");
 constexpr int CONST_DW = LROWS * PITCH; // the constant block of the BatchNorm-shift row (16 bytes per plane, buffer 0)
 
 // tile row of (c,kh) row R = c*7 + kh (for the lane's output row 0)
@@ -121,8 +120,8 @@ constexpr int tile_row(int R) { return (R / 7) * TR + R % 7; }
 // output rows).  Producer waves stream the raw rows from HBM, pool them and write the two fp16
 // planes (two copies each) of the NEXT item's tile into the other half of an LDS double buffer;
 // consumer waves run the MFMAs and the sign/pack epilogue of the CURRENT item.  One workgroup
-// barrier per item.  Consumer wave w owns units w, w+8, ...: all of one M-tile (u & 1 = w & 1);
-// waves w and w+4 share a SIMD and carry 4 + 3 units.  BatchNorm is folded: its scale into the
+// barrier per item.  MT = M-tiles of 32 output channels (1, 2 or 4: p <= 32, 64, 128).  Consumer wave w owns units
+// w, w+8, ...: all of one M-tile (u % MT = w % MT); at MT = 2 waves w and w+4 share a SIMD and carry 4 + 3 units.  BatchNorm is folded: its scale into the
 // weights (host), its shift into the initial value of the accumulators, so the epilogue is the
 // sign bit alone.
 //
@@ -136,7 +135,7 @@ constexpr int tile_row(int R) { return (R / 7) * TR + R % 7; }
 // CP = also emit the channel-word layout (read only by the two-launch gate kernels of gate.hip: --layers 3 / 4,
 // x-small, TTNET_GATE_UNFUSED); the block-fused gate path reads rows alone, and the word formation and its
 // cross-lane exchange are then compiled out of the epilogue.
-template <bool U8, bool CP>
+template <bool U8, bool CP, int MT>
 __global__ __launch_bounds__(STEM_THREADS) void stem_pc_kernel(const void *__restrict__ xin, const uint4 *__restrict__ wfrag,
                                                                const float *__restrict__ init, uint64_t *__restrict__ rp,
                                                                uint16_t *__restrict__ cp, int p, int n_images,
@@ -145,8 +144,10 @@ __global__ __launch_bounds__(STEM_THREADS) void stem_pc_kernel(const void *__res
   const uint8_t *xu8 = (const uint8_t *)xin;
   extern __shared__ __align__(16) uint8_t smem[];
   uint32_t *tiles = (uint32_t *)smem;                                              // [2][TILE_DW]
-  uint32_t(*stage)[64][NT + 2] = (uint32_t(*)[64][NT + 2])(smem + 2 * TILE_DW * 4);   // [2][64][NT+2]
-  uint32_t *s_norm = (uint32_t *)(smem + 2 * TILE_DW * 4 + 2 * 64 * (NT + 2) * 4);    // U8: [3][1024] h1 | h2 << 16
+  static_assert(!CP || MT == 2, "the channel-word layout is built for p = 64");
+  constexpr int CH = 32 * MT, UNITS = NT * MT;                                     // channels the kernel carries; (N-tile, M-tile) pairs of one item
+  uint32_t(*stage)[CH][NT + 2] = (uint32_t(*)[CH][NT + 2])(smem + 2 * TILE_DW * 4);   // [2][CH][NT+2]
+  uint32_t *s_norm = (uint32_t *)(smem + 2 * TILE_DW * 4 + 2 * CH * (NT + 2) * 4);    // U8: [3][1024] h1 | h2 << 16
   if constexpr (U8)
     for (int i = threadIdx.x; i < 3 * 1024; i += STEM_THREADS) s_norm[i] = norm_tab[i];
   const int H = 224, W = 224;
@@ -161,9 +162,9 @@ __global__ __launch_bounds__(STEM_THREADS) void stem_pc_kernel(const void *__res
     const uint32_t cb = (uint32_t)__builtin_bit_cast(uint16_t, (_Float16)init[0]);
     tiles[(threadIdx.x >> 2) * PLANE_DW + CONST_DW + (threadIdx.x & 3)] = threadIdx.x == 0 ? (cb | (cb << 16)) : 0u;
   }
-  if (threadIdx.x < 128) {
-    stage[threadIdx.x >> 6][threadIdx.x & 63][NT] = 0;
-    stage[threadIdx.x >> 6][threadIdx.x & 63][NT + 1] = 0;
+  for (int i = threadIdx.x; i < 2 * CH; i += STEM_THREADS) {
+    stage[i / CH][i % CH][NT] = 0;
+    stage[i / CH][i % CH][NT + 1] = 0;
   }
 
   // ---- items ---------------------------------------------------------------------------------
@@ -372,8 +373,8 @@ __global__ __launch_bounds__(STEM_THREADS) void stem_pc_kernel(const void *__res
     if constexpr (kStemSkip & 32) return;
     int n, oy0;
     item_of(j, n, oy0);
-    for (int idx = threadIdx.x - 64 * CONS_WAVES; idx < 64 * SR; idx += 64 * PROD_WAVES) {
-      const int ch = idx & 63, row = idx >> 6;
+    for (int idx = threadIdx.x - 64 * CONS_WAVES; idx < CH * SR; idx += 64 * PROD_WAVES) {
+      const int ch = idx % CH, row = idx / CH;
       const int b0 = 56 * row, w0 = b0 >> 5, sft = b0 & 31;
       const uint64_t lo = st[ch][w0] | ((uint64_t)st[ch][w0 + 1] << 32);
       const uint64_t hi = st[ch][w0 + 2];
@@ -386,12 +387,13 @@ __global__ __launch_bounds__(STEM_THREADS) void stem_pc_kernel(const void *__res
   // ---- consumer side -----------------------------------------------------------------------
   const int h = lane >> 5, col = lane & 31;
   const DwLaneConst tk = dw_lane_const(lane);
-  const int m = wave & 1;                                // this wave's M-tile (consumers only)
-  const int nunits = (UNITS - wave + CONS_WAVES - 1) / CONS_WAVES;     // 4 (waves 0-3) or 3
+  const int m = wave % MT;                               // this wave's M-tile (consumers only)
+  constexpr int TSTEP = CONS_WAVES / MT;                 // N-tiles between two units of a wave
+  const int nunits = (UNITS - wave + CONS_WAVES - 1) / CONS_WAVES;     // MT = 2: 4 (waves 0-3) or 3
   // byte offset, inside a tile buffer, of dword 0 of the lane's window in plane 0 and tile row 0:
   // pixel pp of the item -> output row pp / 56, column ox; odd columns read copy 1
   auto unit_addr = [&](int i) -> uint32_t {
-    const uint32_t t = (uint32_t)(wave >> 1) + (uint32_t)(CONS_WAVES / 2) * (uint32_t)i;
+    const uint32_t t = (uint32_t)(wave / MT) + (uint32_t)TSTEP * (uint32_t)i;
     const uint32_t pp = 32u * t + (uint32_t)col, oyl = pp / 56u, ox = pp - 56u * oyl, par = ox & 1u;
     return 4u * (2u * oyl * PITCH + (ox - par) + par * COPY_DW);
   };
@@ -509,7 +511,7 @@ __global__ __launch_bounds__(STEM_THREADS) void stem_pc_kernel(const void *__res
 #pragma unroll
     for (int ks = 0; ks < KSTEPS; ++ks)
 #pragma unroll
-      for (int pl = 0; pl < NPL; ++pl) wreg[ks][pl] = wfrag[((ks * NPL + pl) * 2 + m) * 64 + lane];
+      for (int pl = 0; pl < NPL; ++pl) wreg[ks][pl] = wfrag[((ks * NPL + pl) * MT + m) * 64 + lane];
     STEM_STAMP(0, 0);
     __syncthreads();
     __syncthreads();
@@ -534,7 +536,7 @@ __global__ __launch_bounds__(STEM_THREADS) void stem_pc_kernel(const void *__res
       for (int i = 0; i < nunits; ++i) {
         const uint32_t a = unit_addr(i) + buf, an = unit_addr(i + 1 < nunits ? i + 1 : i) + buf;
         const uint32_t a1 = a + hrow1, a15 = a + hrow15, a10 = h ? a_shift : a, an1 = an + hrow1, an15 = an + hrow15;
-        const int tprev = (wave >> 1) + (CONS_WAVES / 2) * (i - 1);
+        const int tprev = wave / MT + TSTEP * (i - 1);
         unsigned long long f[KSTEPS + 2][4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -567,10 +569,10 @@ __global__ __launch_bounds__(STEM_THREADS) void stem_pc_kernel(const void *__res
           q1[e] = f[KSTEPS + 1][e];
         }
         pend = sign_bits(acc);
-        if constexpr (CP) channel_words(pend, (wave >> 1) + (CONS_WAVES / 2) * i, n, oy0);
+        if constexpr (CP) channel_words(pend, wave / MT + TSTEP * i, n, oy0);
       }
       // the last unit's transpose has no MFMAs to hide under
-      static_for<0, 5>([&](auto pc) { epi_piece(pc, pend, (wave >> 1) + (CONS_WAVES / 2) * (nunits - 1), st, true); });
+      static_for<0, 5>([&](auto pc) { epi_piece(pc, pend, wave / MT + TSTEP * (nunits - 1), st, true); });
       STEM_STAMP(0, 3 + j);
       __syncthreads();
     }
@@ -605,7 +607,10 @@ static float f16_to_f32(uint16_t h) {
 
 // init[0] = the constant c of the shift row (a power of two); returns false if the folded BatchNorm
 // shift is too large for it (|shift| x weight prescale x 16 >= 2^30).
+static int stem_mtiles(int p) { return p <= 32 ? 1 : (p <= 64 ? 2 : 4); }
+
 bool stem_split_weights(const float *w, const double *scale, const double *shift, int p, uint16_t *out, float *init) {
+  const int MT = stem_mtiles(p), CH = 32 * MT;
   // BatchNorm scale folded into the weights (float32 product, like any other float32 rounding of
   // the reference's conv + BN chain); the shift becomes the weights of the 22nd (c,kh) row, whose
   // "pixels" are the constant c in slots 0 and 1: slot 0 carries shift / c to 22 bits (two fp16
@@ -614,8 +619,8 @@ bool stem_split_weights(const float *w, const double *scale, const double *shift
   for (int ch = 0; ch < p; ++ch)
     for (int i = 0; i < 147; ++i) wf[(size_t)ch * 147 + i] = (float)((double)w[(size_t)ch * 147 + i] * scale[ch]);
   const float ws = weight_prescale(wf.data(), wf.size());
-  double sh[64], amax = 0.0;
-  for (int ch = 0; ch < 64; ++ch) {
+  double sh[128], amax = 0.0;
+  for (int ch = 0; ch < CH; ++ch) {
     sh[ch] = ch < p ? shift[ch] * (double)ws * (double)X_PRESCALE : -1.0;      // channels beyond p: bit 0
     amax = std::max(amax, std::fabs(sh[ch]));
   }
@@ -626,7 +631,7 @@ bool stem_split_weights(const float *w, const double *scale, const double *shift
   for (int i = 0; i < 64; ++i) init[i] = 0.f;
   init[0] = (float)c;
   for (int ks = 0; ks < KSTEPS; ++ks)
-    for (int m = 0; m < 2; ++m)
+    for (int m = 0; m < MT; ++m)
       for (int l = 0; l < 64; ++l) {
         const int ch = 32 * m + (l & 31), R = 2 * ks + (l >> 5);
         double resid = 0.0;
@@ -644,13 +649,13 @@ bool stem_split_weights(const float *w, const double *scale, const double *shift
           const uint16_t h2 = f32_to_f16_rne((float)(v - (double)f16_to_f32(h1)));
           if (R == 21 && j == 0) resid = v - (double)f16_to_f32(h1) - (double)f16_to_f32(h2);
           const uint16_t parts[NPL] = {h1, h2};
-          for (int pl = 0; pl < NPL; ++pl) out[((((size_t)ks * NPL + pl) * 2 + m) * 64 + l) * 8 + j] = parts[pl];
+          for (int pl = 0; pl < NPL; ++pl) out[((((size_t)ks * NPL + pl) * MT + m) * 64 + l) * 8 + j] = parts[pl];
         }
       }
   return true;
 }
 
-size_t stem_split_weights_elems() { return (size_t)KSTEPS * NPL * 2 * 64 * 8; }
+size_t stem_split_weights_elems() { return (size_t)KSTEPS * NPL * 4 * 64 * 8; }      // (sized for four M-tiles: p <= 128)
 
 // U8 input: table [3][1024] of split pooled values, indexed by the integer sum of the four bytes
 void stem_norm_table(const float mean[3], const float stdv[3], uint32_t *tab) {
@@ -673,15 +678,16 @@ int stem_kernel_arg_sizes(const int **sizes) {
 
 int launch_stem(const void *x, bool x_is_u8, const uint32_t *norm_tab, const void *wfrag, const float *init, uint64_t *rp,
                 uint16_t *cp, int n, int p, uint32_t *range_flag, hipStream_t s) {
-  if (p < 1 || p > 64 || (cp && p != 64)) {
-    set_error("stem: p=%d outside [1,64] (channel words need p = 64)", p);
+  if (p < 1 || p > 128 || (cp && p != 64)) {
+    set_error("stem: p=%d outside [1,128] (channel words need p = 64)", p);
     return TTNET_E_UNSUPPORTED;
   }
+  const int MT = stem_mtiles(p);
   if (((uintptr_t)x & (x_is_u8 ? 3 : 15)) != 0) {
     set_error("stem: the input must be %d-byte aligned", x_is_u8 ? 4 : 16);
     return TTNET_E_INVALID;
   }
-  const size_t lds = (size_t)2 * TILE_DW * 4 + (size_t)2 * 64 * (NT + 2) * 4 + (x_is_u8 ? 3 * 1024 * 4 : 0);
+  const size_t lds = (size_t)2 * TILE_DW * 4 + (size_t)2 * 32 * MT * (NT + 2) * 4 + (x_is_u8 ? 3 * 1024 * 4 : 0);
   const int items = n * NBLK;
   const int grid = std::min(items, 256);
   auto launch = [&](auto kernel) -> int {
@@ -690,8 +696,10 @@ int launch_stem(const void *x, bool x_is_u8, const uint32_t *norm_tab, const voi
                        range_flag);
     return TTNET_OK;
   };
-  if (x_is_u8) TT_TRY(cp ? launch(stem_pc_kernel<true, true>) : launch(stem_pc_kernel<true, false>));
-  else TT_TRY(cp ? launch(stem_pc_kernel<false, true>) : launch(stem_pc_kernel<false, false>));
+  if (cp) TT_TRY(x_is_u8 ? launch(stem_pc_kernel<true, true, 2>) : launch(stem_pc_kernel<false, true, 2>));
+  else if (MT == 1) TT_TRY(x_is_u8 ? launch(stem_pc_kernel<true, false, 1>) : launch(stem_pc_kernel<false, false, 1>));
+  else if (MT == 2) TT_TRY(x_is_u8 ? launch(stem_pc_kernel<true, false, 2>) : launch(stem_pc_kernel<false, false, 2>));
+  else TT_TRY(x_is_u8 ? launch(stem_pc_kernel<true, false, 4>) : launch(stem_pc_kernel<false, false, 4>));
   TT_HIP(hipGetLastError());
   return TTNET_OK;
 }

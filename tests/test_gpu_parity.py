@@ -555,7 +555,9 @@ def test_errors_are_loud(small_model, dev):
     assert lib.ttnet_plan_create(C.byref(desc), 0, C.byref(h)) == -1
     desc = _lib.NetDesc(0, 8, 5, 1, 224, 224, 4, 0)      # small at p = 40: a fan-in of 20, no truth-table kernel (p = 16..64 in steps of 16 are built)
     assert lib.ttnet_plan_create(C.byref(desc), 0, C.byref(h)) == -4 and b"% 16" in lib.ttnet_last_error()
-    desc = _lib.NetDesc(0, 12, 8, 1, 224, 224, 4, 0)     # small at p = 96: beyond the stem kernel's two M-tiles
+    desc = _lib.NetDesc(0, 20, 8, 1, 224, 224, 4, 0)     # small at p = 160: beyond the stem kernel's four M-tiles
+    assert lib.ttnet_plan_create(C.byref(desc), 0, C.byref(h)) == -4
+    desc = _lib.NetDesc(0, 4, 8, 3, 224, 224, 4, 0)      # --layers 3 at p = 32: the stride-1 blocks are built for p = 64
     assert lib.ttnet_plan_create(C.byref(desc), 0, C.byref(h)) == -4
     with pytest.raises(RuntimeError):
         model(torch.zeros((1, 3, 32, 32), device=dev))
@@ -615,6 +617,12 @@ def _check_geometry_against_the_oracle(dev, nfilter, tfilter, layers, golden=Non
         y = m(torch.from_numpy(x).to(dev)).cpu().numpy()
     stem_rows = m.read_stage("features.3", 3)
     bits = OB.unpack_rows(stem_rows, 56)
+    # 0. the stem (one, two or four M-tiles by p): bits of the float oracle's stem except at near ties
+    taps = {}
+    OF.forward(torch.from_numpy(x[:2]), OF.to_torch_state(st), spec, taps)
+    ref_bits, pre = taps["features.3"].numpy().astype(np.uint8), taps["stem.pre"].numpy()
+    d = np.argwhere(bits[:2] != ref_bits)
+    assert all(abs(pre[tuple(i)]) < OB.NEAR_TIE for i in d), f"{tag}: stem bits differ away from a near tie"
     # 1. tables: GPU float64 == numpy float64 (differences only where the oracle itself sees a near tie)
     luts = {}
     with ThreadPoolExecutor(max_workers=8) as ex:
@@ -671,11 +679,11 @@ def test_other_depths_against_the_oracle(dev, layers):
     _check_geometry_against_the_oracle(dev, 8, 8, layers, f"ref_small_l{layers}.npz" if layers >= 3 else None)
 
 
-@pytest.mark.parametrize("nfilter,tfilter", [(4, 8), (6, 8), (2, 8)])
+@pytest.mark.parametrize("nfilter,tfilter", [(4, 8), (6, 8), (2, 8), (12, 8), (16, 8)])
 def test_other_widths_against_the_oracle(dev, nfilter, tfilter):
-    """p = nfilter * tfilter other than main.py's default 64 (TT_general_imagenet_v2_small.py:165-167): 32, 48, 16.
-    Every p with p % 16 == 0 and p <= 64 keeps the fan-in of 16 and is built; p = 32 is also pinned to the imported
-    reference (tests/golden/ref_small_p32.npz)."""
+    """p = nfilter * tfilter other than main.py's default 64 (TT_general_imagenet_v2_small.py:165-167): 32, 48, 16, 96, 128.
+    Every p with p % 16 == 0 and p <= 128 keeps the fan-in of 16 and is built (one, two or four M-tiles in the stem
+    kernel); p = 32 is also pinned to the imported reference (tests/golden/ref_small_p32.npz)."""
     p = nfilter * tfilter
     _check_geometry_against_the_oracle(dev, nfilter, tfilter, 1, "ref_small_p32.npz" if p == 32 else None)
 
@@ -689,7 +697,7 @@ def test_xsmall_other_widths_against_the_oracle(dev, nfilter, tfilter):
 def test_unbuilt_widths_are_refused_loudly(dev):
     """What the reference constructs and this build does not (ttnet.h): p > 64, and p with another fan-in than 16."""
     from argparse import Namespace
-    for nf, tf in ((12, 8), (5, 8)):                 # p = 96 (> 64), p = 40 (fan-in 20)
+    for nf, tf in ((20, 8), (5, 8)):                 # p = 160 (> 128), p = 40 (fan-in 20)
         try:
             m = ttnet.TT_vf_19lv3_imgnet_small(Namespace(nfilter=nf, tfilter=tf, layers=1, groups=[1, None, 4, None]))
         except (ValueError, RuntimeError, AssertionError):
