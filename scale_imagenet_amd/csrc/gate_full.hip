@@ -391,13 +391,14 @@ __global__ __launch_bounds__(512) void full_pw_mfma_kernel(FullPwArgs a) {
 // float64 one -- provided tau really bounds the error.  tau (per output channel, computed by the kernel from
 // the weights it stages): with A_m = sum_c |w1[m][c]|, zmax_m = |s1_m| A_m + |t1_m| (no hidden unit can exceed it),
 //     ez_m = |s1_m| A_m (2^-21 + 16 x 2^-24) + 3 x 2^-24 zmax_m       layer 1: operand split, accumulation, BatchNorm fma
-//     eg_m = 1.13 ez_m + 2.4e-6 (zmax_m + 0.1)                         GELU: its slope, its own error (below: gelu_node_fast)
+//     eg_m = 1.13 ez_m + 1.6e-6 + 2e-7 zmax_m                          GELU: its slope, its own error (below: gelu_lin_node)
 //     E    = sum_m |w2[o][m]| eg_m + 3.2e-6 sum_m |w2[o][m]| |g_m|     layer 2: both operand splits, the dropped
 //                                                                      low x low product, 32 roundings of the sum
 //     tau  = 2 (|s2_o| E + 2^-22 |t2_o|)                               factor 2: margin
-// The second sum of E is the pixel's own: one more matrix instruction per k-step on |w2| x |g| (the high halves
-// with their sign bits cleared, which under-states either factor by at most 2^-11: the 3.2 for 3.1) accumulates
-// it beside the outputs -- with the worst case |g_m| <= zmax_m in its place the list was twice as long.
+// The second sum of E is the pixel's own: one more matrix instruction per k-step on |w2| x g (the high halves, which
+// under-state either factor by at most 2^-11: the 3.2 for 3.1; g signed, since |g| <= g + 0.34 -- gelu >= -0.17 --
+// and 0.35 sum |w2| goes into the constant part) accumulates it beside the outputs -- with the worst case
+// |g_m| <= zmax_m in its place the list was twice as long.
 // On the synthetic model about 1 in 1000 (pixel, group) pairs is listed.  The last block emits relu'd float32
 // features for a float32 head (tolerance 1e-5 on the logits): it takes the fast evaluation as it stands.
 //
@@ -438,23 +439,45 @@ __device__ inline int gelu_node(float zs, float &dz) {
   return (int)r + kPhiN / 2;
 }
 __device__ inline float gelu_eval(float zs, float dz, const float4 &c) { return zs * fmaf(dz, fmaf(dz, c.z, c.y), c.x); }
-// The node without a round, a convert and an index shift: t = 2^23 x 1.5 + (argument in units of 1/32) holds a
-// node in its low mantissa bits (round to nearest even, like rint), so  t - magic  is the node as a float and
-// (bits of t) << 4 plus a constant is the byte address of its table entry.  NOT always the nearest node: the shift
-// operand sh2m = 32 shift + magic is itself rounded to an integer (the float32 ulp at 1.5 x 2^23 is 1), so the node is
-// the nearest one of (argument - delta), |delta| <= 1/2 node: |dz| <= 1/32 instead of 1/64, the neglected cubic term
-// 8 x larger.  dz is formed from the node actually taken, so the quadratic is still the expansion around that node;
-// its error is |gelu - gelu_f32| <= 2.4e-6 (|z| + 0.1) (tests/test_full_fast_bounds.py restates this function with
-// the rounded shift: 0.54 of that bound at worst), which is what eg_m of full_pw_fast_kernel uses.  d, sc2, sh2: the matrix instruction's
-// output and BatchNorm scale / shift pre-multiplied by 32 / SCALE (sh2 with the magic number added); zs = the same
-// value in units of 1 / SCALE.  Six vector instructions with gelu_eval's three.
+// full_pw_fast_kernel's GELU (round 3): a table of gelu ITSELF, kGelN = 4096 nodes z_i = (i - 2048) / 256 on [-8, 8), evaluated
+// as the tangent at the NEAREST node.  |u - i| <= 1/2 node = 1/512 in z, so the neglected term is <= (1/512)^2 / 2 x
+// max |gelu''| (= 2 pdf(0) = 0.798) = 1.53e-6; an entry holds the tangent as a line in u itself, (intercept, slope) with
+// intercept = SCALE gelu(z_i) - i x slope (from the ROUNDED slope, so that the slope's rounding is not multiplied by u), and
+// g = fma(u, slope, intercept) has the roundings of the intercept and of the fma: 2^-24 (|intercept| + |g|) <= 2e-7 |z|.
+//   |gelu_lin(z) - gelu(z)| <= 1.6e-6 + 2e-7 |z|      (tests/test_full_fast_bounds.py restates it in float32 on a dense grid)
+// Five vector instructions and one 8-byte LDS read per hidden value where the quadratic in Phi of rounds 2 took nine and a
+// 12-byte read -- the kernel is bound by vector issue -- and a bound that no longer grows 2.4e-6 per unit of zmax:
+//   u = fma(d, 256 sc, 256 sh)          the BatchNorm output in node widths
+//   t = med3(u + magic, lo, hi)         magic = 1.5 x 2^23: the float32 add rounds u to the nearest integer (ties to even),
+//                                       which then sits in the low mantissa bits; the clamp keeps it inside the table
+//   entry address = (bits of t) << 3 + constant;   g = fma(u, slope, intercept)
+// Beyond the table: node 0 holds (0, 0) (|gelu(z)| < 1e-14 for z <= -8), node 4095 holds (0, SCALE / 256): gelu(z) = z
+// to 1e-14 for z >= 7.99, and that IS the line.
 constexpr float kNodeMagic = 12582912.0f;            // 1.5 x 2^23
-template <int SCALE>
-__device__ inline uint32_t gelu_node_fast(float d, float sc2, float sh2m, float zs, float &dz, uint32_t addr_k) {
-  float t = fmaf(d, sc2, sh2m);
-  t = __builtin_fminf(__builtin_fmaxf(t, kNodeMagic - (float)(kPhiN / 2)), kNodeMagic + (float)(kPhiN / 2 - 1));
-  dz = fmaf(t - kNodeMagic, -(float)SCALE / 32.0f, zs);
-  return (__float_as_uint(t) << 4) + addr_k;
+constexpr int kGelN = 4096;
+__device__ inline void gelu_table_to_lds(float2 *dst, const double *erf_tab, double scale) {
+  for (int i = threadIdx.x; i < kGelN; i += blockDim.x) {
+    const double z = (double)(i - kGelN / 2) * (1.0 / 256.0);
+    const double x = z * 0.70710678118654752440, ax = __builtin_fabs(x);
+    int k = (int)(ax * 8.0);
+    k = k < kErfN - 1 ? k : kErfN - 1;
+    const double t = ax - ((double)k + 0.5) * 0.125;
+    const double *c = erf_tab + k * kErfC;
+    double p = c[8];
+    for (int q = 7; q >= 0; --q) p = fma(p, t, c[q]);
+    p = ax >= 6.0 ? 1.0 : p;
+    const double Phi = 0.5 * (1.0 + __builtin_copysign(p, x));
+    const double pdf = 0.39894228040143267794 * exp(-0.5 * z * z);
+    const float slope = (float)(scale * (Phi + z * pdf) * (1.0 / 256.0));
+    float2 e = make_float2((float)(scale * z * Phi - (double)(i - kGelN / 2) * (double)slope), slope);
+    if (i == 0) e = make_float2(0.f, 0.f);
+    if (i == kGelN - 1) e = make_float2(0.f, (float)(scale * (1.0 / 256.0)));
+    dst[i] = e;
+  }
+}
+__device__ inline uint32_t gelu_lin_node(float u, uint32_t addr_k) {
+  const float t = __builtin_amdgcn_fmed3f(u + kNodeMagic, kNodeMagic - (float)(kGelN / 2), kNodeMagic + (float)(kGelN / 2 - 1));
+  return (__float_as_uint(t) << 3) + addr_k;
 }
 template <int SCALE>
 __device__ inline float gelu_f32(float zs, const float4 *tab) {
@@ -498,7 +521,7 @@ __device__ unsigned long long g_pw_stamps[8];        // ns spent by wave 0 of bl
 template <int OT>
 constexpr size_t fast_lds_bytes() {
   return (size_t)kFastMT * 2 * 64 * 16 + (size_t)kFastKP * OT * 2 * 64 * 16 + 4 * 256 * sizeof(float) + 3 * 32 * sizeof(float) + 64 +
-         (size_t)kPhiN * 16 + 32 * sizeof(float) + (size_t)kFastKP * OT * 64 * 16 + 2 * 256 * sizeof(float);
+         (size_t)kGelN * 8 + 32 * sizeof(float) + (size_t)kFastKP * OT * 64 * 16 + 2 * 256 * sizeof(float);
 }
 
 template <int OT>      // 16-row output tiles: 2 (cout = 30) or 1 (cout = 15)
@@ -510,15 +533,15 @@ __global__ __launch_bounds__(512, TT_FULLPW_MINWAVES) void full_pw_fast_kernel(F
   constexpr int CIN = kFastCin, MT = kFastMT, KP = kFastKP, MID = kFastMid;
   uint4 *w1f = (uint4 *)lds_raw;                                // [MT][plane][lane]: layer-1 A fragments
   uint4 *w2f = w1f + MT * 2 * 64;                               // [KP][OT][plane][lane]: layer-2 A fragments
-  float *s1f = (float *)(w2f + KP * OT * 2 * 64);               // [256] BatchNorm1 scale / layer-1 prescale
-  float *t1f = s1f + 256, *zmx = t1f + 256, *egm = zmx + 256;   // [256] each: shift; zmax_m; eg_m
+  float *s1f = (float *)(w2f + KP * OT * 2 * 64);               // [256] (unused since round 3: the node computation carries the BatchNorm)
+  float *t1f = s1f + 256, *zmx = t1f + 256, *egm = zmx + 256;   // [256] each: (unused); zmax_m; eg_m
 
   float *s2f = egm + 256, *t2f = s2f + 32, *tau = t2f + 32;     // [32] each (tau: the part of the bound that does not depend on the pixel)
   float *tauk = tau + 32;                                       // [32] bound per unit of the accumulated |w2| x |g|
   float *red = tauk + 32;                                       // [16] reductions
-  float4 *phi = (float4 *)(red + 16);                           // [512] GELU table
-  uint4 *w2a = (uint4 *)(phi + kPhiN);                          // [KP][OT][lane]: |w2|, high halves, layer-2 fragment order
-  float *s1n = (float *)(w2a + KP * OT * 64), *t1n = s1n + 256; // [256] each: scale, shift + magic number of the node computation (gelu_node_fast)
+  float2 *gel = (float2 *)(red + 16);                           // [4096] GELU table: value, slope per node
+  uint4 *w2a = (uint4 *)(gel + kGelN);                          // [KP][OT][lane]: |w2|, high halves, layer-2 fragment order
+  float *s1n = (float *)(w2a + KP * OT * 64), *t1n = s1n + 256; // [256] each: BatchNorm scale / layer-1 prescale and shift, in node widths (gelu_lin_node)
   __shared__ double erf_tab[kErfN * kErfC];
   erf_table_to_lds(erf_tab);
   const int g = blockIdx.x, cout = a.cout;
@@ -538,7 +561,7 @@ __global__ __launch_bounds__(512, TT_FULLPW_MINWAVES) void full_pw_fast_kernel(F
     }
     if (threadIdx.x == 0) red[15] = 0.f;
     __syncthreads();
-    phi_table_to_lds(phi, erf_tab, (double)ACT_PRESCALE);
+    gelu_table_to_lds(gel, erf_tab, (double)ACT_PRESCALE);
     m1 = 0.f;
     m2 = 0.f;
     for (int w = 0; w < nwaves; ++w) {
@@ -577,32 +600,30 @@ __global__ __launch_bounds__(512, TT_FULLPW_MINWAVES) void full_pw_fast_kernel(F
         const double sc = a.s1[g * MID + m], sh = a.t1[g * MID + m];
         const double zmax = fabs(sc) * A + fabs(sh);
         const double ez = fabs(sc) * A * (4.76837158203125e-7 + 16.0 * 5.9604644775390625e-8) + 3.0 * 5.9604644775390625e-8 * zmax;
-        s1f[m] = (float)(sc * (double)ACT_PRESCALE / (double)ws1);
-        t1f[m] = (float)(sh * (double)ACT_PRESCALE);
-        s1n[m] = (float)(sc * 32.0 / (double)ws1);
-        t1n[m] = (float)(sh * 32.0 + (double)kNodeMagic);
+        s1n[m] = (float)(sc * 256.0 / (double)ws1);
+        t1n[m] = (float)(sh * 256.0);
         zmx[m] = (float)zmax;
-        egm[m] = (float)(1.13 * ez + 2.4e-6 * (zmax + 0.1));       // (gelu_node_fast: |dz| <= 1/32)
+        egm[m] = (float)(1.13 * ez + 1.6e-6 + 2e-7 * zmax);        // (gelu_lin_node)
         if (!(zmax * (double)ACT_PRESCALE < 65000.0)) red[15] = 1.0f;     // |gelu(z)| <= |z| <= zmax: only then can a split overflow
       } else {
-        s1f[m] = 0.f; t1f[m] = 0.f; zmx[m] = 0.f; egm[m] = 0.f; s1n[m] = 0.f; t1n[m] = kNodeMagic;
+        zmx[m] = 0.f; egm[m] = 0.f; s1n[m] = 0.f; t1n[m] = 0.f;
       }
     }
     __syncthreads();
     if (threadIdx.x < 32) {
       const int o = threadIdx.x;
       if (o < cout) {
-        double E = 0.0, S2 = 0.0;
+        double E = 0.0, S1 = 0.0;
         for (int m = 0; m < MID; ++m) {
           const double w = fabs((double)a.w2[((size_t)g * cout + o) * MID + m]);
           E += w * (double)egm[m];
-          S2 += w * (double)zmx[m];
+          S1 += w;
         }
-        (void)S2;                                        // (the worst case of the sum the kernel now accumulates per pixel)
         const double sc = a.s2[g * cout + o], sh = a.t2[g * cout + o];
         s2f[o] = (float)(sc / ((double)ws2 * (double)ACT_PRESCALE));
         t2f[o] = (float)sh;
-        tau[o] = (float)(2.0 * (fabs(sc) * E + 2.384185791015625e-7 * fabs(sh))) * a.tau_scale;
+        // (the pixel's own sum |w2| |g| is accumulated as sum |w2| g <= that, plus at most 0.34 sum |w2|: gelu >= -0.17)
+        tau[o] = (float)(2.0 * (fabs(sc) * (E + 3.2e-6 * 0.35 * S1) + 2.384185791015625e-7 * fabs(sh))) * a.tau_scale;
         tauk[o] = (float)(2.0 * fabs(sc) * 3.2e-6 / ((double)ws2 * (double)ACT_PRESCALE)) * a.tau_scale;
       } else {
         s2f[o] = 0.f; t2f[o] = -1.0f; tau[o] = 0.f; tauk[o] = 0.f;
@@ -617,8 +638,8 @@ __global__ __launch_bounds__(512, TT_FULLPW_MINWAVES) void full_pw_fast_kernel(F
   const uint32_t cap = (uint32_t)a.n * (uint32_t)a.H * (uint32_t)a.W;
   bool out_of_range = false;
   const bool check_range = red[15] != 0.f;               // (block-uniform; false for any sane BatchNorm)
-  // gelu_node_fast: byte address of table entry i = phi + 16 i, i = (bits of t) - (bits of the magic number) + 256
-  const uint32_t phi_k = (uint32_t)((uint8_t *)phi - lds_raw) + 16u * (uint32_t)(kPhiN / 2) - (0x4B400000u << 4);
+  // gelu_lin_node: byte address of table entry i = gel + 8 i, i = (bits of t) - (bits of the magic number) + 2048
+  const uint32_t gel_k = (uint32_t)((uint8_t *)gel - lds_raw) + 8u * (uint32_t)(kGelN / 2) - (0x4B400000u << 3);
 #ifdef TT_FULLPW_STAMP
   const bool stamping = blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0;
   unsigned long long stamp_t = 10ull * __builtin_amdgcn_s_memrealtime();
@@ -673,7 +694,6 @@ __global__ __launch_bounds__(512, TT_FULLPW_MINWAVES) void full_pw_fast_kernel(F
         const int mt = 2 * kp + hf;
         if ((kPwSkip & 4) == 0 && mt < MT) {
           const f16x8 wa = __builtin_bit_cast(f16x8, w1f[(mt * 2 + 0) * 64 + lane]), wb = __builtin_bit_cast(f16x8, w1f[(mt * 2 + 1) * 64 + lane]);
-          const f32x4 sc = *(const f32x4 *)(s1f + 16 * mt + 4 * lg), sh = *(const f32x4 *)(t1f + 16 * mt + 4 * lg);
           const f32x4 scn = *(const f32x4 *)(s1n + 16 * mt + 4 * lg), shn = *(const f32x4 *)(t1n + 16 * mt + 4 * lg);
           // All four pixel tiles of the hidden tile at once: eight matrix instructions, then sixteen independent
           // BatchNorm / node computations, sixteen table reads in flight, sixteen evaluations.  (Tile by tile, every
@@ -683,21 +703,21 @@ __global__ __launch_bounds__(512, TT_FULLPW_MINWAVES) void full_pw_fast_kernel(F
           for (int nt = 0; nt < 4; ++nt) d[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb, __builtin_bit_cast(f16x8, xb[nt]), f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
 #pragma unroll
           for (int nt = 0; nt < 4; ++nt) d[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa, __builtin_bit_cast(f16x8, xb[nt]), d[nt], 0, 0, 0);
-          float zs[16], dz[16];
+          float u[16];
           uint32_t node[16];                            // LDS byte address of the table entry
 #pragma unroll
           for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
             for (int i = 0; i < 4; ++i) {               // register i = hidden unit 16 mt + 4 (l/16) + i
-              zs[4 * nt + i] = fmaf(d[nt][i], sc[i], sh[i]);
-              node[4 * nt + i] = gelu_node_fast<(int)ACT_PRESCALE>(d[nt][i], scn[i], shn[i], zs[4 * nt + i], dz[4 * nt + i], phi_k);
+              u[4 * nt + i] = fmaf(d[nt][i], scn[i], shn[i]);
+              node[4 * nt + i] = gelu_lin_node(u[4 * nt + i], gel_k);
             }
-          float4 cf[16];
+          float2 cf[16];
 #pragma unroll
-          for (int e = 0; e < 16; ++e) cf[e] = *(const float4 *)(lds_raw + node[e]);
+          for (int e = 0; e < 16; ++e) cf[e] = *(const float2 *)(lds_raw + node[e]);
           float gv[16];
 #pragma unroll
-          for (int e = 0; e < 16; ++e) gv[e] = gelu_eval(zs[e], dz[e], cf[e]);
+          for (int e = 0; e < 16; ++e) gv[e] = fmaf(u[e], cf[e].y, cf[e].x);
           if (check_range)
 #pragma unroll
             for (int e = 0; e < 16; ++e) out_of_range |= split_out_of_range(gv[e]);
@@ -711,8 +731,11 @@ __global__ __launch_bounds__(512, TT_FULLPW_MINWAVES) void full_pw_fast_kernel(F
               const f32x2 v = {gv[4 * nt + 2 * pr], gv[4 * nt + 2 * pr + 1]};
               const f16x2 hi = __builtin_convertvector(v, f16x2);
               f32x2 rest;
-              rest.x = v.x - (float)hi.x;
-              rest.y = v.y - (float)hi.y;
+              // v - (float)hi, exact, in one instruction each: v_fma_mix_f32 reads the fp16 half directly (the compiler
+              // converts back first: one more vector instruction per hidden value)
+              const uint32_t hib = __builtin_bit_cast(uint32_t, hi);
+              asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(rest.x) : "v"(hib), "v"(v.x));
+              asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(rest.y) : "v"(hib), "v"(v.y));
               const f16x2 lo = __builtin_convertvector(rest, f16x2);
               g1[nt][2 * hf + pr] = __builtin_bit_cast(uint32_t, hi);
               g2[nt][2 * hf + pr] = __builtin_bit_cast(uint32_t, lo);
@@ -741,9 +764,10 @@ __global__ __launch_bounds__(512, TT_FULLPW_MINWAVES) void full_pw_fast_kernel(F
           const f16x8 wabs = __builtin_bit_cast(f16x8, w2a[(kp * OT + ot) * 64 + lane]);
 #pragma unroll
           for (int nt = 0; nt < 4; ++nt) {
-            const f16x8 babs = __builtin_bit_cast(f16x8, make_uint4(g1[nt][0] & 0x7FFF7FFFu, g1[nt][1] & 0x7FFF7FFFu, g1[nt][2] & 0x7FFF7FFFu,
-                                                                     g1[nt][3] & 0x7FFF7FFFu));
-            accb[ot][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wabs, babs, accb[ot][nt], 0, 0, 0);
+            // |g| <= g + 0.34 (gelu >= -0.17): the signed high halves go in as they are and the constant part,
+            // 0.34 sum |w2|, sits in tau[o] -- sixteen sign-clearing instructions per k-step fewer
+            const f16x8 b1 = __builtin_bit_cast(f16x8, make_uint4(g1[nt][0], g1[nt][1], g1[nt][2], g1[nt][3]));
+            accb[ot][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wabs, b1, accb[ot][nt], 0, 0, 0);
           }
         }
       }

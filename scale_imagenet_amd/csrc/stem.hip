@@ -689,7 +689,8 @@ int launch_stem(const void *x, bool x_is_u8, const uint32_t *norm_tab, const voi
   }
   const size_t lds = (size_t)2 * TILE_DW * 4 + (size_t)2 * 32 * MT * (NT + 2) * 4 + (x_is_u8 ? 3 * 1024 * 4 : 0);
   const int items = n * NBLK;
-  const int grid = std::min(items, 256);
+  static const int grid_cap = getenv("TTNET_STEM_GRID") ? atoi(getenv("TTNET_STEM_GRID")) : 256;      // (diagnostic)
+  const int grid = std::min(items, std::max(1, grid_cap));
   auto launch = [&](auto kernel) -> int {
     TT_TRY(ensure_dynamic_lds((const void *)kernel, lds));
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(STEM_THREADS), lds, s, x, (const uint4 *)wfrag, init, rp, cp, p, n, norm_tab,
