@@ -455,6 +455,7 @@ __device__ inline float gelu_eval(float zs, float dz, const float4 &c) { return 
 // to 1e-14 for z >= 7.99, and that IS the line.
 constexpr float kNodeMagic = 12582912.0f;            // 1.5 x 2^23
 constexpr int kGelN = 4096;
+// (dst: LDS, or the plan's copy in global memory -- launch_full_gelu_tables -- which the kernels then only copy)
 __device__ inline void gelu_table_to_lds(float2 *dst, const double *erf_tab, double scale) {
   for (int i = threadIdx.x; i < kGelN; i += blockDim.x) {
     const double z = (double)(i - kGelN / 2) * (1.0 / 256.0);
@@ -474,6 +475,15 @@ __device__ inline void gelu_table_to_lds(float2 *dst, const double *erf_tab, dou
     if (i == kGelN - 1) e = make_float2(0.f, (float)(scale * (1.0 / 256.0)));
     dst[i] = e;
   }
+}
+__device__ inline void gelu_table_copy(float2 *dst, const float *src) {
+  for (int i = threadIdx.x; i < kGelN / 2; i += blockDim.x) ((float4 *)dst)[i] = ((const float4 *)src)[i];
+}
+__global__ void gelu_tables_kernel(float *dst) {
+  __shared__ double erf_tab[kErfN * kErfC];
+  erf_table_to_lds(erf_tab);
+  __syncthreads();
+  gelu_table_to_lds((float2 *)dst + (size_t)blockIdx.x * kGelN, erf_tab, blockIdx.x ? (double)ACT_PRESCALE : 1.0);
 }
 __device__ inline uint32_t gelu_lin_node(float u, uint32_t addr_k) {
   const float t = __builtin_amdgcn_fmed3f(u + kNodeMagic, kNodeMagic - (float)(kGelN / 2), kNodeMagic + (float)(kGelN / 2 - 1));
@@ -561,7 +571,8 @@ __global__ __launch_bounds__(512, TT_FULLPW_MINWAVES) void full_pw_fast_kernel(F
     }
     if (threadIdx.x == 0) red[15] = 0.f;
     __syncthreads();
-    gelu_table_to_lds(gel, erf_tab, (double)ACT_PRESCALE);
+    if (a.gel) gelu_table_copy(gel, a.gel);
+    else gelu_table_to_lds(gel, erf_tab, (double)ACT_PRESCALE);
     m1 = 0.f;
     m2 = 0.f;
     for (int w = 0; w < nwaves; ++w) {
@@ -863,19 +874,28 @@ __global__ __launch_bounds__(512, TT_FULLPW_MINWAVES) void full_pw_fast_kernel(F
 // rounded once from float64), float32 BatchNorm / GELU / second layer, and a bound tau on that evaluation's
 // error; an output with |pre| < tau goes on a list and full_dw_fix_kernel re-evaluates it in float64, in
 // full_dw_tab_kernel's order of summation, so the emitted bits are those of the float64 kernel.
-//     ez_m = |s1_m| A_m (2 KH) 2^-24 + 3 x 2^-24 zmax_m     table entries, KH-1 adds, the BatchNorm fma
-//     eg_m = 1.13 ez_m + 4e-7 (zmax_m + 0.1)
+//     ez_m = 2 KH 2^-24 zmax_m                              the row tables hold 256 (s1 x partial sum (+ t1 in row 0)), the
+//                                                           BatchNorm output in node widths of the GELU table: KH entries
+//                                                           rounded once each and KH - 1 adds, each <= 2^-24 x 256 zmax_m
+//                                                           (the factor 2: margin)
+//     eg_m = 1.13 ez_m + 1.6e-6 + 2e-7 zmax_m               gelu_lin_node (the 1x1 kernel's tangent-line table, scale 1)
 //     E    = sum_m |w2_m| eg_m + 10 x 2^-24 sum_m |w2_m| zmax_m       eight fmas
 //     tau  = 2 (|s2| E + 2^-22 |t2|)
 // If the list overflows (it holds 1/16 of the outputs; about 1 in 10^5 is listed) the fix kernel recomputes
-// every output instead.
+// every output instead.  Round 3: the BatchNorm folded into the tables and the tangent-line GELU -- per hidden value
+// KH table reads, KH - 1 adds, add / med3 / shift-add for the node, one 8-byte read and two fmas, where the quadratic in
+// Phi took eighteen vector instructions.
 template <int KH, int KW>
 __global__ __launch_bounds__(256) void full_dw_fast_kernel(FullDwArgs a) {
   __shared__ float tab[8][KH][1 << KW];
-  __shared__ float s1f[8], t1f[8], w2f[8], s2f, t2f, tauf;
-  __shared__ float4 phi[kPhiN];
+  __shared__ float w2f[8], s2f, t2f, tauf;
+  __shared__ __align__(16) float2 gel[kGelN];
   __shared__ double erf_tab[kErfN * kErfC];
-  erf_table_to_lds(erf_tab);
+  if (!a.gel) {
+    erf_table_to_lds(erf_tab);
+    __syncthreads();
+    gelu_table_to_lds(gel, erf_tab, 1.0);
+  } else gelu_table_copy(gel, a.gel);
   const int c = blockIdx.x;
   constexpr int nk = KH * KW;
   for (int i = threadIdx.x; i < 8 * KH * (1 << KW); i += blockDim.x) {
@@ -883,10 +903,8 @@ __global__ __launch_bounds__(256) void full_dw_fast_kernel(FullDwArgs a) {
     double sum = 0.0;
 #pragma unroll
     for (int kw = 0; kw < KW; ++kw) sum += ((bits >> kw) & 1) ? (double)a.w1[(size_t)c * 8 * nk + m * nk + kh * KW + kw] : 0.0;
-    tab[m][kh][bits] = (float)sum;
+    tab[m][kh][bits] = (float)(256.0 * (a.s1[c * 8 + m] * sum + (kh == 0 ? a.t1[c * 8 + m] : 0.0)));
   }
-  __syncthreads();
-  phi_table_to_lds(phi, erf_tab, 1.0);
   if (threadIdx.x == 0) {
     double E = 0.0, S2 = 0.0;
     for (int m = 0; m < 8; ++m) {
@@ -894,11 +912,9 @@ __global__ __launch_bounds__(256) void full_dw_fast_kernel(FullDwArgs a) {
       for (int k = 0; k < nk; ++k) A += fabs((double)a.w1[(size_t)c * 8 * nk + m * nk + k]);
       const double sc = a.s1[c * 8 + m], sh = a.t1[c * 8 + m], w = (double)a.w2[c * 8 + m];
       const double zmax = fabs(sc) * A + fabs(sh);
-      const double ez = fabs(sc) * A * (2.0 * KH) * 5.9604644775390625e-8 + 3.0 * 5.9604644775390625e-8 * zmax;
-      E += fabs(w) * (1.13 * ez + 4e-7 * (zmax + 0.1));
+      const double ez = (2.0 * KH) * 5.9604644775390625e-8 * zmax;
+      E += fabs(w) * (1.13 * ez + 1.6e-6 + 2e-7 * zmax);
       S2 += fabs(w) * zmax;
-      s1f[m] = (float)sc;
-      t1f[m] = (float)sh;
       w2f[m] = (float)w;
     }
     E += 10.0 * 5.9604644775390625e-8 * S2;
@@ -909,6 +925,7 @@ __global__ __launch_bounds__(256) void full_dw_fast_kernel(FullDwArgs a) {
   __syncthreads();
   const int rows = a.n * a.ho;
   const uint32_t cap = a.fix_cap;
+  const uint32_t gel_k = 8u * (uint32_t)(kGelN / 2) - (0x4B400000u << 3);        // byte offset of entry i inside gel = (bits of t) << 3 + this
   for (int t = blockIdx.y * blockDim.x + threadIdx.x; t < rows; t += gridDim.y * blockDim.x) {
     const int n = t / a.ho, oy = t % a.ho;
     uint64_t r[KH];
@@ -922,13 +939,21 @@ __global__ __launch_bounds__(256) void full_dw_fast_kernel(FullDwArgs a) {
       uint32_t idx[KH];
 #pragma unroll
       for (int kh = 0; kh < KH; ++kh) idx[kh] = (uint32_t)(r[kh] >> (ox * a.stride)) & ((1u << KW) - 1u);
-      float acc = 0.f;
+      float u[8];
+      uint32_t node[8];
 #pragma unroll
       for (int m = 0; m < 8; ++m) {
         float sm = tab[m][0][idx[0]];
 #pragma unroll
         for (int kh = 1; kh < KH; ++kh) sm += tab[m][kh][idx[kh]];
-        acc = fmaf(gelu_f32<1>(fmaf(sm, s1f[m], t1f[m]), phi), w2f[m], acc);
+        u[m] = sm;
+        node[m] = gelu_lin_node(sm, gel_k);
+      }
+      float acc = 0.f;
+#pragma unroll
+      for (int m = 0; m < 8; ++m) {
+        const float2 cf = *(const float2 *)((const uint8_t *)gel + node[m]);
+        acc = fmaf(fmaf(u[m], cf.y, cf.x), w2f[m], acc);
       }
       const float pre = fmaf(acc, s2f, t2f);
       out |= (uint64_t)(pre >= 0.f) << (ox + a.pad_l);
@@ -1046,6 +1071,13 @@ static float full_tau_scale() {
   const char *e = getenv("TTNET_FULL_TAU_SCALE");
   const float v = e ? (float)atof(e) : 1.0f;
   return v > 0.f ? v : 1.0f;
+}
+
+size_t full_gelu_tables_elems() { return (size_t)2 * kGelN * 2; }
+int launch_full_gelu_tables(float *dst, hipStream_t s) {
+  hipLaunchKernelGGL(gelu_tables_kernel, dim3(2), dim3(256), 0, s, dst);
+  TT_HIP(hipGetLastError());
+  return TTNET_OK;
 }
 
 int launch_full_dw(const FullDwArgs &a_in, hipStream_t s) {

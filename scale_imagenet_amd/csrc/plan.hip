@@ -116,6 +116,7 @@ struct ttnet_plan {
   float *last_float = nullptr;      // full variant: relu'd output of the last block before AvgPool2d
   uint32_t *full_fix = nullptr;     // full variant: [64] counters + the pixel lists of one grouped 1x1 block (gate_full.hip)
   size_t full_fix_cap = 0;          // list entries
+  float *full_gel = nullptr;        // full variant: GELU tables of the fast kernels (launch_full_gelu_tables), shared by all lanes
 
   // stem
   uint16_t *stem_wt = nullptr;      // fp16 x 2 split weights, fragment order
@@ -495,6 +496,11 @@ int alloc_workspace(ttnet_plan *pl) {
       }
       pl->full_fix_cap = cap * (size_t)nb;
       TT_TRY(dev_alloc(pl, &pl->full_fix, 64 + pl->full_fix_cap, true, ws));
+      if (!pl->full_gel) {
+        TT_TRY(dev_alloc(pl, &pl->full_gel, full_gelu_tables_elems(), false, ws));
+        TT_TRY(launch_full_gelu_tables(pl->full_gel, nullptr));
+        TT_HIP(hipDeviceSynchronize());
+      }
     }
   }
   const int nb_pad = (nb + 255) / 256 * 256;          // the lin1 GEMM walks whole 256-row tiles
@@ -714,6 +720,7 @@ int run_full_block(ttnet_plan *pl, size_t i, int n, hipStream_t s) {
     a.w1 = wts(b, ".conv1.weight"); a.w2 = wts(b, ".conv2.weight");
     a.s1 = b.s1; a.t1 = b.t1; a.s2 = b.s2; a.t2 = b.t2;
     a.out = o64[br];
+    a.gel = pl->full_gel;
     if (pl->full_fix) {                                // (the list area is shared with the 1x1 blocks: launches are ordered)
       a.fix_count = pl->full_fix;
       a.fix_list = pl->full_fix + 64;
@@ -732,6 +739,7 @@ int run_full_block(ttnet_plan *pl, size_t i, int n, hipStream_t s) {
     a.w1 = wts(b, ".conv1.weight"); a.w2 = wts(b, ".conv2.weight");
     a.s1 = b.s1; a.t1 = b.t1; a.s2 = b.s2; a.t2 = b.t2;
     a.out_rp = mh.c3_tmp; a.out_float = nullptr;
+    a.gel = pl->full_gel ? pl->full_gel + full_gelu_tables_elems() / 2 : nullptr;
     a.fix_count = pl->full_fix; a.fix_list = pl->full_fix ? pl->full_fix + 64 : nullptr; a.range_flag = pl->range_dev;
     static const char *const kC3[4] = {"full.conv3.f4", "full.conv3.f5", "full.conv3.f6", "full.conv3.f7"};
     TT_TIMED(pl, kC3[std::min<size_t>(i, 3)], s, launch_full_pw(a, s));
@@ -749,6 +757,7 @@ int run_full_block(ttnet_plan *pl, size_t i, int n, hipStream_t s) {
     for (int k = 0; k < 4; ++k) a.src[k] = o64[k];
     a.w1 = wts(b, ".conv1.weight"); a.w2 = wts(b, ".conv2.weight");
     a.s1 = b.s1; a.t1 = b.t1; a.s2 = b.s2; a.t2 = b.t2;
+    a.gel = pl->full_gel ? pl->full_gel + full_gelu_tables_elems() / 2 : nullptr;
     a.fix_count = pl->full_fix; a.fix_list = pl->full_fix ? pl->full_fix + 64 : nullptr; a.range_flag = pl->range_dev;
     if (mh.last) {
       a.out_rp = nullptr; a.out_float = pl->last_float;

@@ -284,6 +284,7 @@ struct FullDwArgs {
   uint32_t *fix_list, *fix_count;   // ids of up to fix_cap outputs; one counter
   uint32_t fix_cap;
   float tau_scale;          // as FullPwArgs
+  const float *gel;         // launch_full_gelu_tables' table for scale 1 (nullptr: the kernel builds its own copy)
 };
 struct FullPwArgs {
   int n, H, W;              // pixel grid
@@ -299,9 +300,14 @@ struct FullPwArgs {
   // evaluation cannot vouch for, [groups][n*H*W] pixel ids and [64] counters; the range flag of the plan
   uint32_t *fix_list, *fix_count, *range_flag;
   float tau_scale;          // 1; TTNET_FULL_TAU_SCALE shrinks the bound to measure its margin (tests only)
+  const float *gel;         // launch_full_gelu_tables' table for the activation prescale (nullptr: built by the kernel)
 };
 int launch_full_dw(const FullDwArgs &a, hipStream_t s);
 int launch_full_pw(const FullPwArgs &a, hipStream_t s);
+// the fast kernels' GELU tables (tangent lines at 4096 nodes): [2][4096][2] float32, scale 1 (depthwise) and the activation
+// prescale (1x1); model-independent, built once per plan
+size_t full_gelu_tables_elems();
+int launch_full_gelu_tables(float *dst, hipStream_t s);
 int launch_rp_majority(const uint64_t *x, uint64_t *out, int n, int C, int H, int W, int Ho, int pad_t, int pad_l,
                        hipStream_t s);
 int launch_full_pool_split(const float *x, void *feat_frag, int n, int C, int H, int W, uint32_t *range_flag, hipStream_t s);
