@@ -72,7 +72,8 @@ typedef enum ttnet_variant {
  *   TTNET_XSMALL   reference: any p with p % 4 == 0 ..., layers 0..4.  built: p in {16, 32, .., 128} (its depthwise tables are
  *                  striped by 16 channels), layers 0..2 (the stride-1 first blocks of layers 3 / 4 exist for TTNET_SMALL only).
  *   TTNET_FULL     reference: p = 60 and the other p for which int(4C / 30) divides 4C (p = 64 does NOT construct,
- *                  SURVEY 2 #2), layers 0..4.  built: those p <= 64, layers 0..2.
+ *                  SURVEY 2 #2), layers 0..3 (its --layers 2 falls through the reference's own branch-padding rules at the 9 x 9
+ *                  input of the fourth block, TT_general_imagenet_v2.py:98-128).  built: those p <= 64, layers 0..1.
  *   TTNET_VALEXNET fixed geometry.
  * image_h = image_w = 224 (32 for TTNET_VALEXNET): the reference's branch-padding rules are keyed by the widths that
  * 224 x 224 produces (:98-139); other input sizes fall through them in the reference and are refused here. */

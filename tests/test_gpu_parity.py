@@ -694,6 +694,40 @@ def test_xsmall_other_widths_against_the_oracle(dev, nfilter, tfilter):
     _check_geometry_against_the_oracle(dev, nfilter, tfilter, 1, None, "xsmall")
 
 
+@pytest.mark.parametrize("layers", [0, 2])
+def test_xsmall_other_depths_against_the_oracle(dev, layers):
+    """The x-small variant at --layers 0 / 2 (TT_general_imagenet_v2_xsmall.py:172-177: two and four stride-2 blocks)."""
+    _check_geometry_against_the_oracle(dev, 8, 8, layers, None, "xsmall")
+
+
+def test_full_depth_0_against_the_float_oracle(dev):
+    """The full (fan-in 30) variant at --layers 0 (TT_general_imagenet_v2.py:161-162: two blocks): no tables to compare, so
+    every stage against the float oracle's taps (bit-identical away from near ties of the float32 oracle) and the logits
+    against the float64 head on the GPU's own features."""
+    from argparse import Namespace
+    from scale_imagenet_amd.spec import make_spec
+    spec = make_spec("full", 6, 10, 0)
+    st = synth.synth_state_dict(spec, calibrated=False)
+    m = ttnet.TT_vf_19lv3_imgnet(Namespace(nfilter=6, tfilter=10, layers=0, groups=[1, None, 4, None]))
+    m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in st.items()}, strict=True)
+    m = m.to(dev).eval().reserve(4)
+    x = synth.synth_images(3)
+    with torch.no_grad():
+        y = m(torch.from_numpy(x).to(dev)).cpu().numpy()
+    taps = {}
+    OF.forward(torch.from_numpy(x), OF.to_torch_state(st), spec, taps)
+    for stage in ["features.3"] + [b.name for b in spec.blocks[:-1]]:
+        got = OB.unpack_rows(m.read_stage(stage, 3), _stage_width(spec, stage))
+        want = taps[stage].numpy().astype(np.uint8)
+        bad = int((got != want).sum())
+        print(f"full --layers 0 {stage}: {bad} of {want.size} bits differ from the float32 oracle")
+        assert bad <= 2, (stage, bad)                # (a float32 near tie of the oracle's own; none seen)
+    feat = m.read_stage("flatten", 3)
+    exact = OB.head64(feat, st, f"features.{4 + len(spec.blocks) + 2}")
+    assert np.abs(feat - taps["flatten"].numpy()).max() <= 2e-5 * max(1.0, float(np.abs(feat).max()))
+    assert np.abs(y - exact).max() <= scaled_tol(exact), np.abs(y - exact).max()
+
+
 def test_unbuilt_widths_are_refused_loudly(dev):
     """What the reference constructs and this build does not (ttnet.h): p > 64, and p with another fan-in than 16."""
     from argparse import Namespace
