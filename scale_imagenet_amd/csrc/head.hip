@@ -23,6 +23,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <type_traits>
 
 #include "ttnet_common.h"
 
@@ -53,26 +54,46 @@ constexpr int G_BM = TT_LIN1_BM, G_BN = 128;          // workgroup tile: (4 | 8)
 constexpr int G_MT = G_BM / 32, G_NT = G_BN / 32;
 constexpr int G_KS = 1;                               // k-steps (of 16) per LDS stage
 constexpr int G_CHUNK = 1024;                         // one fragment block: 64 lanes x 16 B
-constexpr int G_STAGE = (G_MT + G_NT) * G_KS * NP * G_CHUNK;  // 24 KiB
-constexpr int G_STAGES = 4;                           // LDS ring: 3 stages in flight behind the one being read (measured: 6 stages, or 2 k-steps
-                                                      // per stage, change nothing: the kernel is bound by moving its 768 KiB per workgroup)
+constexpr int G_STAGE = (G_MT + G_NT) * G_KS * NP * G_CHUNK;  // 16 KiB (128 x 128 tile)
+#ifndef TT_LIN1_STAGES
+#define TT_LIN1_STAGES 4
+#endif
+constexpr int G_STAGES = TT_LIN1_STAGES;              // LDS ring: G_STAGES - 1 stages issued ahead.  The kernel is bound by how fast a CU takes its
+                                                      // 1 MiB in (about 31 GB/s per CU, 8 TB/s over the chip): in-kernel stamps give 1,000 cycles per
+                                                      // k-step at 4 stages, 970 at 6, 870 at 8 (which fills the LDS), against 384 of MFMAs
 #ifndef TT_LIN1_WAVES
 #define TT_LIN1_WAVES (TT_LIN1_BM / 32)
 #endif
 constexpr int G_WAVES = TT_LIN1_WAVES;                 // wave w: M-tile w % G_MT, N-tiles (w / G_MT) * NPW .. + NPW - 1
 constexpr int G_WN = G_WAVES / G_MT, NPW = G_NT / G_WN;
 static_assert(G_WAVES % G_MT == 0 && G_NT % G_WN == 0, "waves tile the workgroup's output");
-constexpr int G_CHUNKS = (G_MT + G_NT) * G_KS * NP;   // 24 fragment blocks per stage
-constexpr int G_LOADS = (G_CHUNKS + G_WAVES - 1) / G_WAVES;   // direct-to-LDS loads per wave and stage (3; any
+constexpr int G_CHUNKS = (G_MT + G_NT) * G_KS * NP;   // 16 fragment blocks per stage
+// Dedicated loader waves (round 3 experiment, kept as a build option): a direct-to-LDS load costs the wave that issues it
+// 60 - 185 cycles of issue (MI355X_MICROARCH.md, cycle constants), four of them per k-step beside twelve MFMAs of 32 cycles; with
+// TT_LIN1_LOADERS = 4, waves G_WAVES .. issue every load and nothing else.  Measured (tools/ubench/lin1_parts.hip, stamps): the
+// kernel alone 42 -> 40 us, but the forward with two batches in flight 1.79 -> 1.66 M images/s (eight waves per workgroup
+// leave less of the CU to the other batch's kernels): 0 = every wave loads, as shipped.
+#ifndef TT_LIN1_LOADERS
+#define TT_LIN1_LOADERS 0
+#endif
+constexpr int G_LOADERS = TT_LIN1_LOADERS;
+constexpr int G_THREADS = 64 * (G_WAVES + G_LOADERS);
+constexpr int G_LW = G_LOADERS ? G_LOADERS : G_WAVES; // waves that load
+constexpr int G_LOADS = (G_CHUNKS + G_LW - 1) / G_LW; // direct-to-LDS loads per loading wave and stage (any
                                                       // surplus slots load into a scratch block so every wave counts the same)
 constexpr int G_LDS = G_STAGES * G_STAGE + G_CHUNK;
 
+#ifdef TT_LIN1_STAMP
+__device__ unsigned long long g_lin1_stamps[512][2];      // (diagnostic builds: shader cycles and ns of the main loop per workgroup)
+#endif
 // Af: [mtile32][KS][NP][64][8] fp16, Bf: [ntile32][KS][NP][64][8] fp16, part: slabs in accumulator order (epilogue)
-__global__ __launch_bounds__(64 * G_WAVES) void gemm_f16x2_kernel(const uint8_t *__restrict__ Af, const uint8_t *__restrict__ Bf,
+__global__ __launch_bounds__(G_THREADS) void gemm_f16x2_kernel(const uint8_t *__restrict__ Af, const uint8_t *__restrict__ Bf,
                                                          float *__restrict__ part, int M, int N, int KS, int ks_per,
                                                          int n_tiles, int m_tiles, int splits) {
   extern __shared__ __align__(16) uint8_t lds[];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const bool loader = G_LOADERS ? wave >= G_WAVES : true, consumer = wave < G_WAVES;
+  const int lw = G_LOADERS ? (loader ? wave - G_WAVES : 0) : wave;      // index among the loading waves
   // 1-D grid, XCD-aware: blocks b and b+8 share an XCD (round-robin dispatch), so the N-tiles
   // of one (M-tile, K-slice) -- which all read the same A slice -- are given ids that are equal
   // mod 8: the slice is then fetched into that XCD's L2 once instead of once per N-tile.
@@ -102,7 +123,7 @@ __global__ __launch_bounds__(64 * G_WAVES) void gemm_f16x2_kernel(const uint8_t 
   int chunk_lds[G_LOADS];
 #pragma unroll
   for (int jj = 0; jj < G_LOADS; ++jj) {
-    const int c = wave + G_WAVES * jj;
+    const int c = lw + G_LW * jj;
     const bool real = c < G_CHUNKS;
     const bool isA = c < G_MT * G_KS * NP;
     const int cc = real ? (isA ? c : c - G_MT * G_KS * NP) : 0;
@@ -115,7 +136,7 @@ __global__ __launch_bounds__(64 * G_WAVES) void gemm_f16x2_kernel(const uint8_t 
 #pragma unroll
     for (int jj = 0; jj < G_LOADS; ++jj) {
       if constexpr (kLin1Skip & 3) {
-        const bool isA = wave + G_WAVES * jj < G_MT * G_KS * NP;
+        const bool isA = lw + G_LW * jj < G_MT * G_KS * NP;
         if (((kLin1Skip & 1) && isA) || ((kLin1Skip & 2) && !isA)) continue;
       }
       __builtin_amdgcn_global_load_lds(
@@ -135,59 +156,124 @@ __global__ __launch_bounds__(64 * G_WAVES) void gemm_f16x2_kernel(const uint8_t 
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  // Software pipeline.  The loop is latency bound with one stage in flight (an HBM round trip
-  // is longer than a stage of MFMAs), so G_STAGES-1 stages are kept in flight: a counted
-  // s_waitcnt retires the oldest, a raw s_barrier (no vmcnt(0) drain, unlike __syncthreads with
-  // LDS-DMA pending) publishes it, and the slot read in the previous iteration is refilled.
-  for (int p = 0; p < G_STAGES - 1 && p < iters; ++p) issue(p, p);
-  for (int it = 0; it < iters; ++it) {
-    const int younger = min(G_STAGES - 2, iters - 1 - it);       // stages issued after stage `it`
-    static_assert(G_STAGES <= 6, "one s_waitcnt per possible count of younger stages");
-    if (younger >= 4) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * G_LOADS) : "memory");
+  // Software pipeline, two levels.
+  //  * global -> LDS: G_STAGES - 1 stages are issued ahead (an HBM round trip is longer than a stage of MFMAs); a counted
+  //    s_waitcnt retires the oldest needed one and a raw s_barrier (no vmcnt(0) drain, unlike __syncthreads with LDS-DMA pending)
+  //    publishes it.  The barrier at the top of k-step `it` publishes stage it + 1: the fragments of a k-step are read
+  //    during the MFMAs of the k-step before.
+  //  * LDS -> registers (round 3): the in-kernel stamps of tools/ubench/lin1_parts.hip (-DTT_LIN1_STAMP) gave 739 cycles per
+  //    k-step with NO global loads at all -- ten 16-byte fragment reads, a wait for all of them, then twelve MFMAs of 32 cycles
+  //    (384) -- and 912 with the loads: the matrix pipe idled while the fragments arrived.  Now a wave reads the B fragments of
+  //    N-tile j + 2 (of the next k-step for j = 2, 3) and the next A fragments before the three MFMAs of N-tile j; the compiler's
+  //    counted lgkmcnt waits then cover reads issued two tiles (192 matrix cycles) earlier.
+  // Slot (it + 3) % 4 = (it - 1) % 4 is refilled after the barrier of k-step it: its last fragment reads were waited for by the
+  // MFMAs of k-step it - 1, before that barrier.
+  static_assert(G_KS == 1 && MPW == 1 && NPW == 4, "the fragment pipeline below is written for one k-step per stage and four N-tiles per wave");
+  auto wait_landed = [&](int younger) {                // all but the `younger` most recently issued stages have landed
+    if (younger >= 5) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(5 * G_LOADS) : "memory");
+    else if (younger == 4) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * G_LOADS) : "memory");
     else if (younger == 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * G_LOADS) : "memory");
     else if (younger == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * G_LOADS) : "memory");
     else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G_LOADS) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();                      // stage `it` landed for every wave; slot (it-1)%S is free
-    if (it + G_STAGES - 1 < iters) issue(it + G_STAGES - 1, (it + G_STAGES - 1) % G_STAGES);
-    const uint8_t *st = lds + (it % G_STAGES) * G_STAGE;
-#pragma unroll
-    for (int kk = 0; kk < G_KS; ++kk) {
-      f16x8 a[MPW][NP], b[NPW][NP];
-#pragma unroll
-      for (int i = 0; i < MPW; ++i)
-#pragma unroll
-        for (int pl = 0; pl < NP; ++pl)
-          a[i][pl] = *(const f16x8 *)(st + ((((wm + i) * G_KS + kk) * NP + pl) * G_CHUNK) + lane * 16);
-#pragma unroll
-      for (int j = 0; j < NPW; ++j)
-#pragma unroll
-        for (int pl = 0; pl < NP; ++pl)
-          b[j][pl] = *(const f16x8 *)(st + ((G_MT * G_KS * NP + ((wn * NPW + j) * G_KS + kk) * NP + pl) * G_CHUNK) + lane * 16);
-      // the three products of a tile go to the same accumulator: issue them tile-interleaved, so that
-      // consecutive MFMAs are independent (same per-accumulator order: low terms first)
-      if constexpr (kLin1Skip & 4) {
-#pragma unroll
-        for (int j = 0; j < NPW; ++j) acc[0][j][0] += (float)a[0][0][0] + (float)b[j][0][0];      // keep the fragment reads alive
-        continue;
-      }
-#pragma unroll
-      for (int i = 0; i < MPW; ++i) {
-#pragma unroll
-        for (int j = 0; j < NPW; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][1], b[j][0], acc[i][j], 0, 0, 0);
-#pragma unroll
-        for (int j = 0; j < NPW; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][0], b[j][1], acc[i][j], 0, 0, 0);
-#pragma unroll
-        for (int j = 0; j < NPW; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][0], b[j][0], acc[i][j], 0, 0, 0);
-      }
-    }
+  };
+  static_assert(G_STAGES >= 4 && G_STAGES <= 8 && 5 * G_LOADS < 64, "G_STAGES - 1 stages issued ahead; the barrier of k-step it frees slot (it - 1) % G_STAGES");
+#ifdef TT_LIN1_STAMP
+  const unsigned long long st_c = __builtin_amdgcn_s_memtime(), st_r = __builtin_amdgcn_s_memrealtime();
+#endif
+  if (loader) {
+    for (int p = 0; p < G_STAGES - 1 && p < iters; ++p) issue(p, p);
+    wait_landed(min(G_STAGES - 2, iters - 1));         // stage 0
   }
+  __builtin_amdgcn_s_barrier();
+  // The consumer side is written with inline-assembly reads and hand-counted waits (the scheme of stem.hip): left to the
+  // compiler the reads sink next to their use behind s_waitcnt lgkmcnt(0).  LDS operations retire in order, so "all but the N
+  // youngest" is exact.  Queue on entering a k-step: B tile 0 (2 reads), A (2), B tile 1 (2) of this k-step, issued during the last.
+  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+  u32x4 af[2][NP], bq[NPW][NP];      // A fragments of even / odd k-steps (two register sets: a copy would read registers whose load is in flight)
+#define TT_DSRD(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(dst) : "v"(addr), "n"(off))
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void *)lds + (uint32_t)lane * 16u;
+  const uint32_t offA = (uint32_t)(wm * NP) * G_CHUNK, offB = (uint32_t)(G_MT * NP + wn * NPW * NP) * G_CHUNK;
+  auto tile = [&](int j, const u32x4 (&a_cur)[NP]) {
+    if constexpr (kLin1Skip & 4) {
+      acc[0][j][0] += __uint_as_float(a_cur[0][0] ^ bq[j][0][0] ^ bq[j][1][0] ^ a_cur[1][0]);      // keep the fragment reads alive
+    } else {
+      // the three products of a tile go to the same accumulator, low terms first (a single chain of this instruction
+      // issues back to back: MI355X_MICROARCH.md, cycle constants)
+      const f16x8 a0 = __builtin_bit_cast(f16x8, a_cur[0]), a1 = __builtin_bit_cast(f16x8, a_cur[1]);
+      const f16x8 b0 = __builtin_bit_cast(f16x8, bq[j][0]), b1 = __builtin_bit_cast(f16x8, bq[j][1]);
+      acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b0, acc[0][j], 0, 0, 0);
+      acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b1, acc[0][j], 0, 0, 0);
+      acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b0, acc[0][j], 0, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  // Every k-step reads ahead, the last one too (it reads a slot that holds older data and nobody uses the values): one
+  // code path, so that the compiler never has to reconcile two register assignments with a copy of a register whose load is
+  // still in flight -- which is what the peeled last k-step of the first version of this loop did.
+  auto kstep = [&](auto par_c, int it) {
+    constexpr int P = decltype(par_c)::value;          // it % 2
+    u32x4 (&a_cur)[NP] = af[P];
+    u32x4 (&a_nxt)[NP] = af[1 - P];
+    const uint32_t sb = lds0 + (uint32_t)(it % G_STAGES) * G_STAGE + offB;
+    const uint32_t sn = lds0 + (uint32_t)((it + 1) % G_STAGES) * G_STAGE;
+    const uint32_t snb = sn + offB, sna = sn + offA;
+    TT_DSRD(bq[2][0], sb, 4 * G_CHUNK);
+    TT_DSRD(bq[2][1], sb, 5 * G_CHUNK);
+    asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(bq[0][0]), "+v"(bq[0][1]), "+v"(a_cur[0]), "+v"(a_cur[1]));      // in flight: B tiles 1, 2
+    tile(0, a_cur);
+    TT_DSRD(bq[3][0], sb, 6 * G_CHUNK);
+    TT_DSRD(bq[3][1], sb, 7 * G_CHUNK);
+    asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(bq[1][0]), "+v"(bq[1][1]));      // B tiles 2, 3
+    tile(1, a_cur);
+    TT_DSRD(bq[0][0], snb, 0);
+    TT_DSRD(bq[0][1], snb, G_CHUNK);
+    TT_DSRD(a_nxt[0], sna, 0);
+    TT_DSRD(a_nxt[1], sna, G_CHUNK);
+    asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(bq[2][0]), "+v"(bq[2][1]));      // B tile 3; next k-step: B tile 0, A
+    tile(2, a_cur);
+    TT_DSRD(bq[1][0], snb, 2 * G_CHUNK);
+    TT_DSRD(bq[1][1], snb, 3 * G_CHUNK);
+    asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(bq[3][0]), "+v"(bq[3][1]));      // next k-step: B tile 0, A, B tile 1
+    tile(3, a_cur);
+  };
+  if (consumer) {
+    const uint32_t s0 = lds0;
+    TT_DSRD(bq[0][0], s0 + offB, 0);
+    TT_DSRD(bq[0][1], s0 + offB, G_CHUNK);
+    TT_DSRD(af[0][0], s0 + offA, 0);
+    TT_DSRD(af[0][1], s0 + offA, G_CHUNK);
+    TT_DSRD(bq[1][0], s0 + offB, 2 * G_CHUNK);
+    TT_DSRD(bq[1][1], s0 + offB, 3 * G_CHUNK);
+  }
+  auto step = [&](auto par_c, int it) {
+    if (loader) wait_landed(max(0, min(it + G_STAGES - 2, iters - 1) - (it + 1)));      // stage it + 1 (the later ones may still be in flight)
+    __builtin_amdgcn_s_barrier();                      // stage it + 1 landed for every wave; slot (it - 1) % 4 is free
+    if (loader && it + G_STAGES - 1 < iters) issue(it + G_STAGES - 1, (it + G_STAGES - 1) % G_STAGES);
+    if (consumer) kstep(par_c, it);
+  };
+#pragma unroll 1
+  for (int it = 0; it < iters; it += 2) {
+    step(std::integral_constant<int, 0>{}, it);
+    if (it + 1 < iters) step(std::integral_constant<int, 1>{}, it + 1);
+  }
+  // the reads the last k-step issued ahead: wait for them with their registers still allocated
+  if (consumer)
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bq[0][0]), "+v"(bq[0][1]), "+v"(bq[1][0]), "+v"(bq[1][1]), "+v"(af[0][0]), "+v"(af[0][1]),
+                 "+v"(af[1][0]), "+v"(af[1][1]));
+#undef TT_DSRD
   // The partial tile goes out as the accumulators stand -- slab layout [slice][tile32 row][tile32 col][reg / 4][lane][4]
   // -- so that a wave's store is one linear 1 KiB block of 16 bytes per lane (row-major slabs took sixteen
   // 4-byte stores per tile and lane: 8 of the kernel's 45 us at B = 256 were store issue).  Rows / columns of the
   // padding (M to 256, N to 128) are written too; head_mid_kernel reads the same order and drops them.
   // C/D layout: col = lane&31 (N), row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) (M)
+#ifdef TT_LIN1_STAMP
+  if (threadIdx.x == 0 && blockIdx.x < 512) {
+    g_lin1_stamps[blockIdx.x][0] = __builtin_amdgcn_s_memtime() - st_c;
+    g_lin1_stamps[blockIdx.x][1] = 10ull * (__builtin_amdgcn_s_memrealtime() - st_r);
+  }
+#endif
+  if (!consumer) return;
   float4 *dst = (float4 *)part + (size_t)slice * (m_tiles * G_MT) * (n_tiles * G_NT) * 256;
 #pragma unroll
   for (int i = 0; i < MPW; ++i)
@@ -357,7 +443,7 @@ int launch_gemm_f16x2(const void *Af, const void *Bf, float *part, int M, int N,
   }
   TT_TRY(ensure_dynamic_lds((const void *)gemm_f16x2_kernel, G_LDS));
   const int n_tiles = (N + G_BN - 1) / G_BN, m_tiles = (M + G_BM - 1) / G_BM;
-  hipLaunchKernelGGL(gemm_f16x2_kernel, dim3(n_tiles * m_tiles * splits), dim3(64 * G_WAVES), G_LDS, s, (const uint8_t *)Af,
+  hipLaunchKernelGGL(gemm_f16x2_kernel, dim3(n_tiles * m_tiles * splits), dim3(G_THREADS), G_LDS, s, (const uint8_t *)Af,
                      (const uint8_t *)Bf, part, M, N, KS, KS / splits, n_tiles, m_tiles, splits);
   TT_HIP(hipGetLastError());
   return TTNET_OK;

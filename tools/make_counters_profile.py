@@ -12,7 +12,11 @@ LABELS = [("stem_pc_kernel", "stem"), ("gate_last", "gate_last"), ("gemm_f16x2_k
           ("lin1_", "head.lin1"), ("lin2_f16x2_kernel", "head.lin2"), ("head_mid_kernel", "head.bn_poly"),
           ("head_tail", "head.tail"),
           ("gate_block_kernel<56, 29", "gate_block.f4"), ("gate_block_kernel<29, 15", "gate_block.f5"),
-          ("gate_block_kernel<15, 8", "gate_block.f6")]
+          ("gate_block_kernel<15, 8", "gate_block.f6"),
+          ("full_pw_fast_kernel<2>", "full.pw_fast<2>"), ("full_pw_fast_kernel<1>", "full.pw_fast<1>"),
+          ("full_dw_fast_kernel<5, 6>", "full.dw_fast<5,6>"), ("full_dw_fast_kernel<6, 5>", "full.dw_fast<6,5>"),
+          ("full_pw_mfma_kernel<2, true>", "full.pw_fix<2>"), ("full_pw_mfma_kernel<1, true>", "full.pw_fix<1>"),
+          ("full_dw_fix_kernel", "full.dw_fix")]
 
 acc = collections.defaultdict(lambda: collections.defaultdict(lambda: [0.0, 0]))
 for d in sys.argv[2:]:
@@ -20,7 +24,7 @@ for d in sys.argv[2:]:
         for r in csv.DictReader(open(f)):
             a = acc[r["Kernel_Name"]][r["Counter_Name"]]
             a[0] += float(r["Counter_Value"]); a[1] += 1
-out = {"_doc": __doc__.strip().split("\n\n")[1].replace("\n", " "), "batch": 256, "kernels": {}}
+out = {"_doc": __doc__.strip().split("\n\n")[1].replace("\n", " "), "batch": int(os.environ.get("COUNTERS_BATCH", "256")), "kernels": {}}
 for name, cs in acc.items():
     label = next((l for s, l in LABELS if s in name), None)
     if label is None:

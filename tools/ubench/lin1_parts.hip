@@ -6,6 +6,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <vector>
+#include <algorithm>
 
 #include "../../scale_imagenet_amd/csrc/head.hip"
 
@@ -48,5 +49,16 @@ int main(int argc, char **argv) {
     if (i >= 2) tot += ms;
   }
   printf("skip=%d M=%d splits=%d: %.2f us per launch (cold operands)\n", TT_LIN1_SKIP, M, splits, 1e3 * tot / reps);
+#ifdef TT_LIN1_STAMP
+  {
+    static unsigned long long h_st[512][2];
+    (void)hipMemcpyFromSymbol(h_st, HIP_SYMBOL(ttnet::g_lin1_stamps), sizeof(h_st));
+    std::vector<double> cyc, ns;
+    for (int b = 0; b < 256; ++b) { cyc.push_back((double)h_st[b][0]); ns.push_back((double)h_st[b][1]); }
+    std::sort(cyc.begin(), cyc.end()); std::sort(ns.begin(), ns.end());
+    printf("  main loop, median workgroup: %.0f shader cycles, %.0f ns -> %.2f GHz; %.0f cycles per k-step (64 k-steps)\n", cyc[128], ns[128],
+           cyc[128] / ns[128], cyc[128] / 64.0);
+  }
+#endif
   return 0;
 }
