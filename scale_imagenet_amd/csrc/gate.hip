@@ -539,6 +539,7 @@ __global__ __launch_bounds__(256) void gate_last_kernel(GateBlockArgs a, const f
 // shared through LDS; what is left per thread is the 64-byte-row gathers.
 // (The generic kernel above spends ~220 VALU instructions per wave on index arithmetic and is
 // VALU bound: 28 us at B = 256.)
+template <bool NT>
 __global__ __launch_bounds__(256) void gate_last8_kernel(GateBlockArgs a, const float *__restrict__ t_last,
                                                          uint16_t *__restrict__ feat_frag, uint32_t *range_flag,
                                                          const uint32_t *__restrict__ bidx) {
@@ -566,10 +567,11 @@ __global__ __launch_bounds__(256) void gate_last8_kernel(GateBlockArgs a, const 
 #pragma unroll
   for (int sgrp = 0; sgrp < 4; ++sgrp) {
     const float *tab = t_last + (size_t)(4 * wq + sgrp) * 65536 * 16 + k;
-    v[sgrp][0] = tab[s_off[sgrp][p00]];
-    v[sgrp][1] = tab[s_off[sgrp][p00 + 1]];
-    v[sgrp][2] = tab[s_off[sgrp][p00 + 8]];
-    v[sgrp][3] = tab[s_off[sgrp][p00 + 9]];
+    auto ld = [&](uint32_t off) { return NT ? __builtin_nontemporal_load(tab + off) : tab[off]; };
+    v[sgrp][0] = ld(s_off[sgrp][p00]);
+    v[sgrp][1] = ld(s_off[sgrp][p00 + 1]);
+    v[sgrp][2] = ld(s_off[sgrp][p00 + 8]);
+    v[sgrp][3] = ld(s_off[sgrp][p00 + 9]);
   }
 #pragma unroll
   for (int sgrp = 0; sgrp < 4; ++sgrp) {
@@ -694,7 +696,9 @@ int launch_gate_pf(const GateBlockArgs &a, const uint8_t *t_cf, uint16_t *out_cp
 int launch_gate_last(const GateBlockArgs &a, const float *t_last, void *feat_frag, uint32_t *range_flag, hipStream_t s,
                      const uint32_t *idx) {
   if (a.Ho == 8 && a.Wo == 8 && a.n <= 65535) {
-    hipLaunchKernelGGL(gate_last8_kernel, dim3(a.C / 16, a.n), dim3(256), 0, s, a, t_last, (uint16_t *)feat_frag, range_flag, idx);
+    static const bool nt = getenv("TTNET_LAST_NT") && atoi(getenv("TTNET_LAST_NT"));      // (diagnostic: non-temporal table reads)
+    if (nt) hipLaunchKernelGGL(gate_last8_kernel<true>, dim3(a.C / 16, a.n), dim3(256), 0, s, a, t_last, (uint16_t *)feat_frag, range_flag, idx);
+    else hipLaunchKernelGGL(gate_last8_kernel<false>, dim3(a.C / 16, a.n), dim3(256), 0, s, a, t_last, (uint16_t *)feat_frag, range_flag, idx);
     TT_HIP(hipGetLastError());
     return TTNET_OK;
   }

@@ -87,6 +87,7 @@ constexpr int G_LDS = G_STAGES * G_STAGE + G_CHUNK;
 __device__ unsigned long long g_lin1_stamps[512][2];      // (diagnostic builds: shader cycles and ns of the main loop per workgroup)
 #endif
 // Af: [mtile32][KS][NP][64][8] fp16, Bf: [ntile32][KS][NP][64][8] fp16, part: slabs in accumulator order (epilogue)
+template <int AUX_A, int AUX_B>
 __global__ __launch_bounds__(G_THREADS) void gemm_f16x2_kernel(const uint8_t *__restrict__ Af, const uint8_t *__restrict__ Bf,
                                                          float *__restrict__ part, int M, int N, int KS, int ks_per,
                                                          int n_tiles, int m_tiles, int splits) {
@@ -132,18 +133,21 @@ __global__ __launch_bounds__(G_THREADS) void gemm_f16x2_kernel(const uint8_t *__
                     ((((size_t)((isA || !real ? mt0 : nt0) + tl) * KS + ks_beg + kk) * NP + pl) * 64 + lane) * 16;
     chunk_lds[jj] = real ? c * G_CHUNK : -1;
   }
+  // AUX_A / AUX_B: cache policy of the operand loads (0 default, 2 nt)
   auto issue = [&](int it, int buf) {
-#pragma unroll
-    for (int jj = 0; jj < G_LOADS; ++jj) {
+    static_for<0, G_LOADS>([&](auto jc) {
+      constexpr int jj = decltype(jc)::value;
+      constexpr bool allA = G_LW * jj + G_LW - 1 < G_MT * G_KS * NP, allB = G_LW * jj >= G_MT * G_KS * NP;
       if constexpr (kLin1Skip & 3) {
         const bool isA = lw + G_LW * jj < G_MT * G_KS * NP;
-        if (((kLin1Skip & 1) && isA) || ((kLin1Skip & 2) && !isA)) continue;
+        if (((kLin1Skip & 1) && isA) || ((kLin1Skip & 2) && !isA)) return;
       }
-      __builtin_amdgcn_global_load_lds(
-          (const __attribute__((address_space(1))) void *)(chunk_src[jj] + (size_t)it * (G_KS * NP * G_CHUNK)),
-          (__attribute__((address_space(3))) void *)(lds + (chunk_lds[jj] >= 0 ? buf * G_STAGE + chunk_lds[jj] : G_STAGES * G_STAGE)),
-          16, 0, 0);
-    }
+      const auto src = (const __attribute__((address_space(1))) void *)(chunk_src[jj] + (size_t)it * (G_KS * NP * G_CHUNK));
+      const auto dst = (__attribute__((address_space(3))) void *)(lds + (chunk_lds[jj] >= 0 ? buf * G_STAGE + chunk_lds[jj] : G_STAGES * G_STAGE));
+      if constexpr (allA) __builtin_amdgcn_global_load_lds(src, dst, 16, 0, AUX_A);
+      else if constexpr (allB) __builtin_amdgcn_global_load_lds(src, dst, 16, 0, AUX_B);
+      else __builtin_amdgcn_global_load_lds(src, dst, 16, 0, 0);
+    });
   };
 
   constexpr int MPW = 1;                                // M-tiles per wave
@@ -441,10 +445,20 @@ int launch_gemm_f16x2(const void *Af, const void *Bf, float *part, int M, int N,
     set_error("gemm_f16x2: K=%d not divisible into %d slices of %d k-steps", K, splits, G_KS);
     return TTNET_E_UNSUPPORTED;
   }
-  TT_TRY(ensure_dynamic_lds((const void *)gemm_f16x2_kernel, G_LDS));
+  // TTNET_LIN1_NT=<a><b> (diagnostic): non-temporal loads of the A / B operand stream.  Measured (profiles/r03_cache_policy.txt): nt weights
+  // cost the forward with two batches in flight 8 % -- the 66 MB of weights are what the Infinity Cache should keep
+  static const int nt = getenv("TTNET_LIN1_NT") ? atoi(getenv("TTNET_LIN1_NT")) : 0;
   const int n_tiles = (N + G_BN - 1) / G_BN, m_tiles = (M + G_BM - 1) / G_BM;
-  hipLaunchKernelGGL(gemm_f16x2_kernel, dim3(n_tiles * m_tiles * splits), dim3(G_THREADS), G_LDS, s, (const uint8_t *)Af,
-                     (const uint8_t *)Bf, part, M, N, KS, KS / splits, n_tiles, m_tiles, splits);
+  auto launch = [&](auto kernel) -> int {
+    TT_TRY(ensure_dynamic_lds((const void *)kernel, G_LDS));
+    hipLaunchKernelGGL(kernel, dim3(n_tiles * m_tiles * splits), dim3(G_THREADS), G_LDS, s, (const uint8_t *)Af, (const uint8_t *)Bf, part, M, N,
+                       KS, KS / splits, n_tiles, m_tiles, splits);
+    return TTNET_OK;
+  };
+  if (nt == 11) TT_TRY(launch(gemm_f16x2_kernel<2, 2>));
+  else if (nt == 1) TT_TRY(launch(gemm_f16x2_kernel<0, 2>));
+  else if (nt == 10) TT_TRY(launch(gemm_f16x2_kernel<2, 0>));
+  else TT_TRY(launch(gemm_f16x2_kernel<0, 0>));
   TT_HIP(hipGetLastError());
   return TTNET_OK;
 }

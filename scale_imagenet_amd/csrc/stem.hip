@@ -81,7 +81,9 @@ constexpr float X_PRESCALE = ACT_PRESCALE;
 #define TT_STEM_SKIP 0
 #endif
 #ifndef TT_STEM_LOAD_AUX
-#define TT_STEM_LOAD_AUX 0        /* cache policy of the input loads: 0 default, 2 nt */
+#define TT_STEM_LOAD_AUX 2        /* cache policy of the input loads: 0 default, 2 nt (round 3: the input is read once, and left to
+                                     the default policy its 154 MB per batch push tables, weights and the float table out of the Infinity Cache:
+                                     the FORWARD is 5 - 7 % faster with nt, the stem itself unchanged; same-box A/B in profiles/r03_cache_policy.txt) */
 #endif
 #ifndef TT_STEM_PKCVT
 #define TT_STEM_PKCVT 0
@@ -135,7 +137,7 @@ constexpr int tile_row(int R) { return (R / 7) * TR + R % 7; }
 // CP = also emit the channel-word layout (read only by the two-launch gate kernels of gate.hip: --layers 3 / 4,
 // x-small, TTNET_GATE_UNFUSED); the block-fused gate path reads rows alone, and the word formation and its
 // cross-lane exchange are then compiled out of the epilogue.
-template <bool U8, bool CP, int MT>
+template <bool U8, bool CP, int MT, int AUX = TT_STEM_LOAD_AUX>
 __global__ __launch_bounds__(STEM_THREADS) void stem_pc_kernel(const void *__restrict__ xin, const uint4 *__restrict__ wfrag,
                                                                const float *__restrict__ init, uint64_t *__restrict__ rp,
                                                                uint16_t *__restrict__ cp, int p, int n_images,
@@ -269,8 +271,8 @@ __global__ __launch_bounds__(STEM_THREADS) void stem_pc_kernel(const void *__res
         const bool row_ok = load_ok && r < TR && iy >= 0 && iy < 112;
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)img, 0, row_ok ? H * W * 3 : 0, 0x00020000);
         const int soff = row_ok ? 2 * iy * (W * 3) : 0;
-        qa[bi] = __builtin_amdgcn_raw_buffer_load_b96(rs, (int)lane_off8, soff, 0);
-        qb[bi] = __builtin_amdgcn_raw_buffer_load_b96(rs, (int)lane_off8 + W * 3, soff, 0);
+        qa[bi] = __builtin_amdgcn_raw_buffer_load_b96(rs, (int)lane_off8, soff, AUX);
+        qb[bi] = __builtin_amdgcn_raw_buffer_load_b96(rs, (int)lane_off8 + W * 3, soff, AUX);
       };
       static_for<0, 4>([&](auto bic) {
         if constexpr (SPLIT && !(kStemSkip & 2)) split_row(bic);
@@ -351,8 +353,8 @@ __global__ __launch_bounds__(STEM_THREADS) void stem_pc_kernel(const void *__res
           rb[bi] = make_float4(2.f, (float)jl, 1.f, (float)lane);
         } else {
           typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-          const u32x4 a = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)lane_off, soff, TT_STEM_LOAD_AUX);
-          const u32x4 b = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)lane_off + W * 4, soff, TT_STEM_LOAD_AUX);
+          const u32x4 a = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)lane_off, soff, AUX);
+          const u32x4 b = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)lane_off + W * 4, soff, AUX);
           ra[bi] = __builtin_bit_cast(float4, a);
           rb[bi] = __builtin_bit_cast(float4, b);
         }
@@ -699,7 +701,11 @@ int launch_stem(const void *x, bool x_is_u8, const uint32_t *norm_tab, const voi
   };
   if (cp) TT_TRY(x_is_u8 ? launch(stem_pc_kernel<true, true, 2>) : launch(stem_pc_kernel<false, true, 2>));
   else if (MT == 1) TT_TRY(x_is_u8 ? launch(stem_pc_kernel<true, false, 1>) : launch(stem_pc_kernel<false, false, 1>));
-  else if (MT == 2) TT_TRY(x_is_u8 ? launch(stem_pc_kernel<true, false, 2>) : launch(stem_pc_kernel<false, false, 2>));
+  else if (MT == 2) {
+    static const int nt = getenv("TTNET_STEM_NT") ? atoi(getenv("TTNET_STEM_NT")) : TT_STEM_LOAD_AUX;      // (diagnostic: =0 the default cache policy)
+    if (x_is_u8) TT_TRY(nt ? launch(stem_pc_kernel<true, false, 2>) : launch((stem_pc_kernel<true, false, 2, 0>)));
+    else TT_TRY(nt ? launch(stem_pc_kernel<false, false, 2>) : launch((stem_pc_kernel<false, false, 2, 0>)));
+  }
   else TT_TRY(x_is_u8 ? launch(stem_pc_kernel<true, false, 4>) : launch(stem_pc_kernel<false, false, 4>));
   TT_HIP(hipGetLastError());
   return TTNET_OK;
