@@ -530,7 +530,7 @@ __device__ unsigned long long g_pw_stamps[8];        // ns spent by wave 0 of bl
 #endif
 template <int OT>
 constexpr size_t fast_lds_bytes() {
-  return (size_t)kFastMT * 2 * 64 * 16 + (size_t)kFastKP * OT * 2 * 64 * 16 + 4 * 256 * sizeof(float) + 3 * 32 * sizeof(float) + 64 +
+  return (size_t)kFastMT * 2 * 64 * 16 + (size_t)kFastKP * OT * 2 * 64 * 16 + 2 * 256 * sizeof(float) + 3 * 32 * sizeof(float) + 64 +
          (size_t)kGelN * 8 + 32 * sizeof(float) + (size_t)kFastKP * OT * 64 * 16 + 2 * 256 * sizeof(float);
 }
 
@@ -543,8 +543,7 @@ __global__ __launch_bounds__(512, TT_FULLPW_MINWAVES) void full_pw_fast_kernel(F
   constexpr int CIN = kFastCin, MT = kFastMT, KP = kFastKP, MID = kFastMid;
   uint4 *w1f = (uint4 *)lds_raw;                                // [MT][plane][lane]: layer-1 A fragments
   uint4 *w2f = w1f + MT * 2 * 64;                               // [KP][OT][plane][lane]: layer-2 A fragments
-  float *s1f = (float *)(w2f + KP * OT * 2 * 64);               // [256] (unused since round 3: the node computation carries the BatchNorm)
-  float *t1f = s1f + 256, *zmx = t1f + 256, *egm = zmx + 256;   // [256] each: (unused); zmax_m; eg_m
+  float *zmx = (float *)(w2f + KP * OT * 2 * 64), *egm = zmx + 256;   // [256] each: zmax_m; eg_m
 
   float *s2f = egm + 256, *t2f = s2f + 32, *tau = t2f + 32;     // [32] each (tau: the part of the bound that does not depend on the pixel)
   float *tauk = tau + 32;                                       // [32] bound per unit of the accumulated |w2| x |g|
