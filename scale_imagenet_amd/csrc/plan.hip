@@ -121,7 +121,9 @@ struct ttnet_plan {
   // stem
   uint16_t *stem_wt = nullptr;      // fp16 x 2 split weights, fragment order
   float *stem_init = nullptr;       // accumulator start values (folded BN shift), 64 floats
-  uint32_t *norm_tab = nullptr;     // uint8 input: split pooled values per (channel, byte sum), stem_norm_table
+  uint32_t *norm_tab = nullptr;     // uint8 input: centres and border corrections (stem_split_weights_u8)
+  uint16_t *stem_wt_u8 = nullptr;   // uint8 input: split weights with the normalisation folded in
+  float *stem_init_u8 = nullptr;
   float in_mean[3] = {0.485f, 0.456f, 0.406f}, in_std[3] = {0.229f, 0.224f, 0.225f};   // utils/preprocess.py:107-108
   // activations: x_rp[i] / x_cp[i] = input of block i
   std::vector<uint64_t *> x_rp;
@@ -555,13 +557,6 @@ void switch_lane(ttnet_plan *pl, int k) {
   pl->cur = k;
 }
 
-int upload_norm_table(ttnet_plan *pl) {
-  std::vector<uint32_t> tab(3 * 1024);
-  stem_norm_table(pl->in_mean, pl->in_std, tab.data());
-  TT_HIP(hipMemcpy(pl->norm_tab, tab.data(), tab.size() * 4, hipMemcpyHostToDevice));
-  return TTNET_OK;
-}
-
 int allocate(ttnet_plan *pl) {
   size_t *tb = &pl->table_bytes;
   TT_HIP(hipHostMalloc((void **)&pl->range_host, sizeof(uint32_t), hipHostMallocMapped));
@@ -575,8 +570,9 @@ int allocate(ttnet_plan *pl) {
   } else {
     TT_TRY(dev_alloc(pl, &pl->stem_wt, stem_split_weights_elems(), false));
     TT_TRY(dev_alloc(pl, &pl->stem_init, 64, false));
-    TT_TRY(dev_alloc(pl, &pl->norm_tab, 3 * 1024, false));
-    TT_TRY(upload_norm_table(pl));
+    TT_TRY(dev_alloc(pl, &pl->norm_tab, stem_u8_table_elems(), true));
+    TT_TRY(dev_alloc(pl, &pl->stem_wt_u8, stem_split_weights_elems(), true));
+    TT_TRY(dev_alloc(pl, &pl->stem_init_u8, 64, true));
     TT_TRY(dev_alloc(pl, &pl->w1p, (size_t)pl->inter * pl->fcsize, false));
   }
   for (auto &mh : pl->blocks) {
@@ -633,6 +629,27 @@ int fold_bn(ttnet_plan *pl, const std::string &prefix, std::vector<double> &scal
   }
   return TTNET_OK;
 }
+
+// uint8 input: the stem's weights with ToTensor + Normalize folded in (stem.hip, U8).  From the loaded weights and the
+// plan's mean / std: at finalize and again whenever ttnet_plan_set_input_norm changes them.
+int prepare_stem_u8(ttnet_plan *pl) {
+  std::vector<float> w;
+  TT_TRY(fetch(pl->tensors["features.1.weight"], w));
+  std::vector<uint16_t> wf(stem_split_weights_elems());
+  std::vector<uint32_t> tab(stem_u8_table_elems(), 0u);
+  std::vector<double> sc, sh;
+  TT_TRY(fold_bn(pl, "features.2", sc, sh));
+  float init[64];
+  if (!stem_split_weights_u8(w.data(), sc.data(), sh.data(), pl->p, pl->in_mean, pl->in_std, wf.data(), init, tab.data())) {
+    set_error("stem (uint8 input): the folded BatchNorm shift of features.2 is outside the range of the split operands");
+    return TTNET_E_UNSUPPORTED;
+  }
+  TT_HIP(hipMemcpy(pl->stem_wt_u8, wf.data(), wf.size() * 2, hipMemcpyHostToDevice));
+  TT_HIP(hipMemcpy(pl->stem_init_u8, init, sizeof(init), hipMemcpyHostToDevice));
+  TT_HIP(hipMemcpy(pl->norm_tab, tab.data(), tab.size() * 4, hipMemcpyHostToDevice));
+  return TTNET_OK;
+}
+
 
 int upload_f32(float *dst, const std::vector<double> &src) {
   std::vector<float> f(src.begin(), src.end());
@@ -1020,6 +1037,7 @@ int ttnet_plan_finalize(ttnet_plan *pl, void *stream) {
     }
     TT_HIP(hipMemcpy(pl->stem_wt, wf.data(), wf.size() * 2, hipMemcpyHostToDevice));
     TT_HIP(hipMemcpy(pl->stem_init, init, sizeof(init), hipMemcpyHostToDevice));
+    TT_TRY(prepare_stem_u8(pl));
   }
   for (auto &mh : pl->blocks) {
     for (BlockTT *b : {&mh.c1, &mh.c2, &mh.c3, &mh.cf}) TT_TRY(build_table(pl, *b, s));
@@ -1070,7 +1088,7 @@ int forward_eager(ttnet_plan *pl, const void *x_dev, bool u8, int64_t n, float *
     return run_va_tail(pl, (int)n, logits_dev, s);
   }
   TT_TIMED(pl, "stem", s,
-           launch_stem(x_dev, u8, pl->norm_tab, pl->stem_wt, pl->stem_init, pl->x_rp[0], (pl->full || pl->fused || pl->xs) ? nullptr : pl->x_cp[0], (int)n,
+           launch_stem(x_dev, u8, pl->norm_tab, u8 ? pl->stem_wt_u8 : pl->stem_wt, u8 ? pl->stem_init_u8 : pl->stem_init, pl->x_rp[0], (pl->full || pl->fused || pl->xs) ? nullptr : pl->x_cp[0], (int)n,
                        pl->p, pl->range_dev, s));
   return run_from_blocks(pl, (int)n, logits_dev, s);
 }
@@ -1311,7 +1329,9 @@ int ttnet_plan_set_input_norm(ttnet_plan *pl, const float *mean3, const float *s
     pl->in_std[c] = std3[c];
   }
   (void)hipSetDevice(pl->device);
-  return upload_norm_table(pl);
+  if (!pl->finalized) return TTNET_OK;                 // (finalize folds them into the uint8 stem's weights)
+  TT_HIP(hipDeviceSynchronize());                      // no forward may be reading the buffers that are rewritten in place
+  return prepare_stem_u8(pl);
 }
 
 int ttnet_forward_from_stem_bits(ttnet_plan *pl, const uint64_t *rows_dev, int64_t n, float *logits_dev,

@@ -129,11 +129,20 @@ constexpr int tile_row(int R) { return (R / 7) * TR + R % 7; }
 //
 // U8 = true: the input is the decoder's uint8 HWC image and the last two steps of
 // the input pipeline, ToTensor (/255) and Normalize(mean, std) (utils/preprocess.py:104-108),
-// are fused in front of the average pool: the four bytes of a pooled pixel and channel are summed
-// as integers (v_dot4 with a byte selector) and the sum (0..1020) indexes a table of already
-// split values  ((s/4)/255 - mean_c)/std_c x prescale  built on the host in float64.  A quarter of
-// the input bytes, fewer vector instructions; the value is the real-arithmetic one rounded once
-// (the float32 path rounds each pixel and each add: <= 2e-7 apart on a pooled value).
+// are fused in front of the average pool.  Round 3: TWO products instead of three.  The four bytes of a
+// pooled pixel and channel are summed as integers (v_dot4 with a byte selector), s in 0..1020, and the
+// tile holds s - s_c (s_c = round(1020 mean_c)) as ONE fp16 plane -- an integer below 2048 is exact in
+// fp16 -- while the normalisation moves into the weights and a bias:
+//   pre = sum_valid w ((s / 1020 - mean_c) / std_c) + shift
+//       = sum_all (w / (1020 std_c)) (s - s_c)  +  [shift + sum_all w d_c]  -  sum_padded w d_c ,   d_c = (s_c - 1020 mean_c) / (1020 std_c)
+// (a padded tap holds s - s_c = 0 in the tile; |d_c| <= 2.2e-3).  The first term is w2 x + w1 x on the
+// matrix cores, the second the 22nd k-row as for float32 input, the third a per-(border class, channel)
+// correction added to the accumulators before the sign: 16 classes (output row 0 / 1 / interior / 55 x
+// the same for the column: which taps fall into the padding), a table in LDS.  22 instead of 33 matrix
+// instructions per unit, half the fragment reads, one plane written by the producers -- the kernel is
+// bound by the energy of its matrix instructions.  Numerically the same quantity as the
+// float32 path computes from the normalised tensor, to the same ~1e-6; bits are oracle-checked outside
+// the near-tie band (test_uint8_input_fused_normalise).
 // CP = also emit the channel-word layout (read only by the two-launch gate kernels of gate.hip: --layers 3 / 4,
 // x-small, TTNET_GATE_UNFUSED); the block-fused gate path reads rows alone, and the word formation and its
 // cross-lane exchange are then compiled out of the epilogue.
@@ -149,9 +158,15 @@ __global__ __launch_bounds__(STEM_THREADS) void stem_pc_kernel(const void *__res
   static_assert(!CP || MT == 2, "the channel-word layout is built for p = 64");
   constexpr int CH = 32 * MT, UNITS = NT * MT;                                     // channels the kernel carries; (N-tile, M-tile) pairs of one item
   uint32_t(*stage)[CH][NT + 2] = (uint32_t(*)[CH][NT + 2])(smem + 2 * TILE_DW * 4);   // [2][CH][NT+2]
-  uint32_t *s_norm = (uint32_t *)(smem + 2 * TILE_DW * 4 + 2 * CH * (NT + 2) * 4);    // U8: [3][1024] h1 | h2 << 16
-  if constexpr (U8)
-    for (int i = threadIdx.x; i < 3 * 1024; i += STEM_THREADS) s_norm[i] = norm_tab[i];
+  // U8: norm_tab = [4] centres s_c (int32; the 4th unused), then the border corrections [16 classes][MT][2 halves][16 registers] float32
+  constexpr uint32_t CORR_OFF = 2 * TILE_DW * 4 + 2 * CH * (NT + 2) * 4;
+  float *s_corr = (float *)(smem + CORR_OFF);
+  int s_c[3] = {0, 0, 0};
+  if constexpr (U8) {
+    for (int i = threadIdx.x; i < 16 * CH; i += STEM_THREADS) s_corr[i] = __uint_as_float(norm_tab[4 + i]);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) s_c[c] = (int)__builtin_amdgcn_readfirstlane(norm_tab[c]);
+  }
   const int H = 224, W = 224;
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const bool producer = wave >= CONS_WAVES;
@@ -253,14 +268,12 @@ __global__ __launch_bounds__(STEM_THREADS) void stem_pc_kernel(const void *__res
           s1[2] = __builtin_amdgcn_udot4(a.z, 0x01000001u, __builtin_amdgcn_udot4(b.z, 0x01000001u, 0u, false), false);
 #pragma unroll
           for (int c = 0; c < 3; ++c) {
-            const uint32_t e0 = s_norm[c * 1024 + s0[c]] & keep, e1 = s_norm[c * 1024 + s1[c]] & keep;
-            const uint32_t d1 = __builtin_amdgcn_perm(e1, e0, 0x05040100u);      // h1 of both pixels
-            const uint32_t d2 = __builtin_amdgcn_perm(e1, e0, 0x07060302u);      // h2 of both pixels
+            // s - s_c of both pixels as fp16 (exact: |s - s_c| <= 1020), zero in the padding; one plane
+            const float f0 = (float)((int)s0[c] - s_c[c]), f1 = (float)((int)s1[c] - s_c[c]);
+            const uint32_t d1 = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(f0, f1)) & keep;
             uint32_t *dst = tile + (c * TR + r) * PITCH + lane;
             dst[0] = d1;
             dst[COPY_DW - 1] = d1;             // copy 1, one dword to the left (lane 0 lands in unused padding)
-            dst[PLANE_DW] = d2;
-            dst[PLANE_DW + COPY_DW - 1] = d2;
           }
         }
       };
@@ -415,6 +428,10 @@ __global__ __launch_bounds__(STEM_THREADS) void stem_pc_kernel(const void *__res
     }
     constexpr int off = tile_row(2 * ks) * (PITCH * 4);
     const uint32_t a = (ks == 3 ? a15 : (ks == 10 ? a0 : a1)) + (uint32_t)(uintptr_t)smem;
+    if constexpr (U8) {                  // one plane: two reads, v[2] and v[3] stay unused
+      asm volatile("ds_read_b64 %0, %2 offset:%3\n\tds_read_b64 %1, %2 offset:%4" : "=&v"(v[0]), "=&v"(v[1]) : "v"(a), "n"(off), "n"(off + 8));
+      return;
+    }
     asm volatile("ds_read_b64 %0, %4 offset:%5\n\tds_read_b64 %1, %4 offset:%6\n\t"
                  "ds_read_b64 %2, %4 offset:%7\n\tds_read_b64 %3, %4 offset:%8"
                  : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3])
@@ -527,7 +544,7 @@ __global__ __launch_bounds__(STEM_THREADS) void stem_pc_kernel(const void *__res
       const uint32_t buf = (uint32_t)(j & 1) * (TILE_DW * 4);
       uint32_t (*st)[NT + 2] = stage[j & 1];
       // fragments are read two k-steps ahead, across unit boundaries
-      unsigned long long q0[4], q1[4];
+      unsigned long long q0[4] = {0, 0, 0, 0}, q1[4] = {0, 0, 0, 0};
       {
         const uint32_t a = unit_addr(0) + buf;
         read_frag(a + hrow1, a + hrow15, a, std::integral_constant<int, 0>{}, q0);
@@ -541,34 +558,62 @@ __global__ __launch_bounds__(STEM_THREADS) void stem_pc_kernel(const void *__res
         const int tprev = wave / MT + TSTEP * (i - 1);
         unsigned long long f[KSTEPS + 2][4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
+        for (int e = 0; e < (U8 ? 2 : 4); ++e) {
           f[0][e] = q0[e];
           f[1][e] = q1[e];
         }
         f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+        u32x4 cr[4] = {};                    // U8: the border correction of the lane's pixel and sixteen channels
         static_for<0, KSTEPS>([&](auto ksc) {
           constexpr int ks = decltype(ksc)::value;
+          if constexpr (U8 && ks == KSTEPS - 3) {
+            // the pixel's border class (which taps of its window lie in the padding): row 0 / 1 / interior / 55, column likewise
+            const uint32_t tt = (uint32_t)(wave / MT) + (uint32_t)TSTEP * (uint32_t)i;
+            const uint32_t pp = 32u * tt + (uint32_t)col, oyl = pp / 56u, ox = pp - 56u * oyl, oy = (uint32_t)oy0 + oyl;
+            const uint32_t yc = oy == 0u ? 0u : (oy == 1u ? 1u : (oy == 55u ? 3u : 2u));
+            const uint32_t xc = ox == 0u ? 0u : (ox == 1u ? 1u : (ox == 55u ? 3u : 2u));
+            const uint32_t ca = (uint32_t)(uintptr_t)smem + CORR_OFF + ((((yc * 4u + xc) * MT + (uint32_t)m) * 2u + (uint32_t)h) * 64u);
+            asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:16\n\tds_read_b128 %2, %4 offset:32\n\tds_read_b128 %3, %4 offset:48"
+                         : "=&v"(cr[0]), "=&v"(cr[1]), "=&v"(cr[2]), "=&v"(cr[3]) : "v"(ca));
+          }
           if constexpr (ks + 2 < KSTEPS) read_frag(a1, a15, a10, std::integral_constant<int, ks + 2>{}, f[ks + 2]);
           else read_frag(an1, an15, an, std::integral_constant<int, ks + 2 - KSTEPS>{}, f[ks + 2]);
-          // the fragments of k-steps ks+1 and ks+2 (8 reads) may still be in flight
-          if constexpr (!(kStemSkip & 8))
-            asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(f[ks][0]), "+v"(f[ks][1]), "+v"(f[ks][2]), "+v"(f[ks][3]));
           const f16x8 w1 = __builtin_bit_cast(f16x8, wreg[ks][0]), w2 = __builtin_bit_cast(f16x8, wreg[ks][1]);
-          const f16x8 x1 = frag(f[ks][0], f[ks][1]), x2 = frag(f[ks][2], f[ks][3]);
-          if constexpr (kStemSkip & 4) {
-            acc[0] += (float)x1[0] + (float)x2[1] + (float)w1[2] + (float)w2[3];
-          } else {
+          if constexpr (U8) {
+            // LDS operations retire in order; younger than f[ks]: the fragments of k-steps ks+1 and ks+2 (4 reads), and between
+            // k-steps KSTEPS-3 and KSTEPS-2 also the four correction reads issued in front of f[KSTEPS-1]
+            if constexpr (ks == KSTEPS - 3 || ks == KSTEPS - 2) asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(f[ks][0]), "+v"(f[ks][1]));
+            else if constexpr (ks == KSTEPS - 1)
+              asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(f[ks][0]), "+v"(f[ks][1]), "+v"(cr[0]), "+v"(cr[1]), "+v"(cr[2]), "+v"(cr[3]));
+            else asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(f[ks][0]), "+v"(f[ks][1]));
+            const f16x8 x1 = frag(f[ks][0], f[ks][1]);
             acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(w2, x1, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1, x2, acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1, x1, acc, 0, 0, 0);
+          } else {
+            // the fragments of k-steps ks+1 and ks+2 (8 reads) may still be in flight
+            if constexpr (!(kStemSkip & 8))
+              asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(f[ks][0]), "+v"(f[ks][1]), "+v"(f[ks][2]), "+v"(f[ks][3]));
+            const f16x8 x1 = frag(f[ks][0], f[ks][1]), x2 = frag(f[ks][2], f[ks][3]);
+            if constexpr (kStemSkip & 4) {
+              acc[0] += (float)x1[0] + (float)x2[1] + (float)w1[2] + (float)w2[3];
+            } else {
+              acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(w2, x1, acc, 0, 0, 0);
+              acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1, x2, acc, 0, 0, 0);
+              acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1, x1, acc, 0, 0, 0);
+            }
           }
           if constexpr (ks >= 1 && ks <= 5) epi_piece(std::integral_constant<int, ks - 1>{}, pend, tprev, st, i > 0);
           __builtin_amdgcn_sched_barrier(0);     // reads stay two k-steps ahead of their MFMAs, no further
         });
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
+        for (int e = 0; e < (U8 ? 2 : 4); ++e) {
           q0[e] = f[KSTEPS][e];
           q1[e] = f[KSTEPS + 1][e];
+        }
+        if constexpr (U8) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[r] += __uint_as_float(cr[r >> 2][r & 3]);
         }
         pend = sign_bits(acc);
         if constexpr (CP) channel_words(pend, wave / MT + TSTEP * i, n, oy0);
@@ -659,16 +704,88 @@ bool stem_split_weights(const float *w, const double *scale, const double *shift
 
 size_t stem_split_weights_elems() { return (size_t)KSTEPS * NPL * 4 * 64 * 8; }      // (sized for four M-tiles: p <= 128)
 
-// U8 input: table [3][1024] of split pooled values, indexed by the integer sum of the four bytes
-void stem_norm_table(const float mean[3], const float stdv[3], uint32_t *tab) {
-  for (int c = 0; c < 3; ++c)
-    for (int sidx = 0; sidx < 1024; ++sidx) {
-      const double v = ((((double)sidx / 4.0) / 255.0) - (double)mean[c]) / (double)stdv[c] * (double)X_PRESCALE;
-      const float vf = sidx <= 1020 ? (float)v : 0.f;
-      const uint16_t h1 = f32_to_f16_rne(vf);
-      const uint16_t h2 = f32_to_f16_rne(vf - f16_to_f32(h1));
-      tab[c * 1024 + sidx] = (uint32_t)h1 | ((uint32_t)h2 << 16);
+// uint8 input (stem_pc_kernel<true, ..>): the normalisation folded into the weights.  out / init as stem_split_weights, from
+// w / (1020 std_c) and the interior bias shift + sum_all w d_c; tab = [4] centres s_c (int32) + [16 classes][MT][2][16] float32
+// border corrections  - sum_{taps of the class in the padding} w d_c  (x the weight prescale), class = 4 yc + xc, yc / xc =
+// 0: output row / column 0 (taps 0-2 padded), 1: row / column 1 (tap 0), 2: interior, 3: row / column 55 (taps 5, 6).
+size_t stem_u8_table_elems() { return 4 + (size_t)16 * 128; }
+bool stem_split_weights_u8(const float *w, const double *scale, const double *shift, int p, const float mean[3], const float stdv[3],
+                           uint16_t *out, float *init, uint32_t *tab) {
+  const int MT = stem_mtiles(p), CH = 32 * MT;
+  std::vector<float> wf((size_t)p * 147);                 // BatchNorm scale folded in float32, as for float32 input
+  for (int ch = 0; ch < p; ++ch)
+    for (int i = 0; i < 147; ++i) wf[(size_t)ch * 147 + i] = (float)((double)w[(size_t)ch * 147 + i] * scale[ch]);
+  int sc[3];
+  double d[3], k[3];
+  for (int c = 0; c < 3; ++c) {
+    sc[c] = (int)std::lrint(1020.0 * (double)mean[c]);
+    sc[c] = std::min(1020, std::max(0, sc[c]));
+    k[c] = 1.0 / (1020.0 * (double)stdv[c]);
+    d[c] = ((double)sc[c] - 1020.0 * (double)mean[c]) * k[c];
+  }
+  std::vector<float> w2((size_t)p * 147);                 // only to find the prescale
+  for (int ch = 0; ch < p; ++ch)
+    for (int i = 0; i < 147; ++i) w2[(size_t)ch * 147 + i] = (float)((double)wf[(size_t)ch * 147 + i] * k[i / 49]);
+  const float ws = weight_prescale(w2.data(), w2.size());
+  double sh[128], amax = 0.0;
+  for (int ch = 0; ch < CH; ++ch) {
+    double b = -1.0;                                      // channels beyond p: bit 0
+    if (ch < p) {
+      b = shift[ch];
+      for (int i = 0; i < 147; ++i) b += (double)wf[(size_t)ch * 147 + i] * d[i / 49];
     }
+    sh[ch] = b * (double)ws;
+    amax = std::max(amax, std::fabs(sh[ch]));
+  }
+  if (!std::isfinite(amax)) return false;
+  double c = 1.0;
+  while (amax / c > 16384.0 && c < 32768.0) c *= 2.0;
+  if (amax / c > 32768.0) return false;
+  for (int i = 0; i < 64; ++i) init[i] = 0.f;
+  init[0] = (float)c;
+  for (int ks = 0; ks < KSTEPS; ++ks)
+    for (int m = 0; m < MT; ++m)
+      for (int l = 0; l < 64; ++l) {
+        const int ch = 32 * m + (l & 31), R = 2 * ks + (l >> 5);
+        double resid = 0.0;
+        for (int j = 0; j < 8; ++j) {
+          const int kw = j - 1;
+          double v = 0.0;
+          if (R < 21) {
+            if (ch < p && kw >= 0) v = (double)wf[(size_t)ch * 147 + R * 7 + kw] * k[R / 7] * (double)ws;      // R = c*7 + kh
+          } else if (j == 0) {
+            v = sh[ch] / c;
+          } else if (j == 1) {
+            v = resid;
+          }
+          const uint16_t h1 = f32_to_f16_rne((float)v);
+          const uint16_t h2 = f32_to_f16_rne((float)(v - (double)f16_to_f32(h1)));
+          if (R == 21 && j == 0) resid = v - (double)f16_to_f32(h1) - (double)f16_to_f32(h2);
+          const uint16_t parts[NPL] = {h1, h2};
+          for (int pl = 0; pl < NPL; ++pl) out[((((size_t)ks * NPL + pl) * MT + m) * 64 + l) * 8 + j] = parts[pl];
+        }
+      }
+  for (int c3 = 0; c3 < 3; ++c3) tab[c3] = (uint32_t)sc[c3];
+  tab[3] = 0;
+  auto padded = [](int cls, int t) { return cls == 0 ? t <= 2 : (cls == 1 ? t == 0 : (cls == 3 ? t >= 5 : false)); };
+  for (int yc = 0; yc < 4; ++yc)
+    for (int xc = 0; xc < 4; ++xc)
+      for (int m = 0; m < MT; ++m)
+        for (int hh = 0; hh < 2; ++hh)
+          for (int r = 0; r < 16; ++r) {
+            const int ch = 32 * m + (r & 3) + 8 * (r >> 2) + 4 * hh;
+            double corr = 0.0;
+            if (ch < p)
+              for (int i = 0; i < 147; ++i) {
+                const int kh = (i % 49) / 7, kw = i % 7;
+                if (padded(yc, kh) || padded(xc, kw)) corr -= (double)wf[(size_t)ch * 147 + i] * d[i / 49];
+              }
+            const float cf = (float)(corr * (double)ws);
+            uint32_t bits;
+            memcpy(&bits, &cf, 4);
+            tab[4 + ((((size_t)(yc * 4 + xc) * MT + m) * 2 + hh) * 16 + r)] = bits;
+          }
+  return true;
 }
 
 // (x, wfrag, init, rp, cp, p, n, norm_tab, range_flag): keep in step with the kernel's signature
@@ -689,7 +806,7 @@ int launch_stem(const void *x, bool x_is_u8, const uint32_t *norm_tab, const voi
     set_error("stem: the input must be %d-byte aligned", x_is_u8 ? 4 : 16);
     return TTNET_E_INVALID;
   }
-  const size_t lds = (size_t)2 * TILE_DW * 4 + (size_t)2 * 32 * MT * (NT + 2) * 4 + (x_is_u8 ? 3 * 1024 * 4 : 0);
+  const size_t lds = (size_t)2 * TILE_DW * 4 + (size_t)2 * 32 * MT * (NT + 2) * 4 + (x_is_u8 ? (size_t)16 * 32 * MT * 4 : 0);
   const int items = n * NBLK;
   static const int grid_cap = getenv("TTNET_STEM_GRID") ? atoi(getenv("TTNET_STEM_GRID")) : 256;      // (diagnostic)
   const int grid = std::min(items, std::max(1, grid_cap));

@@ -211,10 +211,13 @@ float weight_prescale(const float *w, size_t n);
 // wfrag: the conv weights (BN scale folded in) and, as one more k-row, the folded BN shift, split into two
 // fp16 planes in MFMA fragment order; init[64]: [0] = the constant that row multiplies (both from
 // stem_split_weights, which fails if the shift is out of range)
-// x: float32 NCHW, or (x_is_u8) uint8 NHWC with the normalisation table of stem_norm_table
+// x: float32 NCHW, or (x_is_u8) uint8 NHWC with wfrag / init / norm_tab from stem_split_weights_u8
 int launch_stem(const void *x, bool x_is_u8, const uint32_t *norm_tab, const void *wfrag, const float *init, uint64_t *rp,
                 uint16_t *cp, int n, int p, uint32_t *range_flag, hipStream_t s);
-void stem_norm_table(const float mean[3], const float stdv[3], uint32_t *tab /*[3][1024]*/);
+// uint8 input: weights with the normalisation folded in, centres and border corrections (stem.hip)
+size_t stem_u8_table_elems();
+bool stem_split_weights_u8(const float *w, const double *scale, const double *shift, int p, const float mean[3], const float stdv[3],
+                           uint16_t *out, float *init, uint32_t *tab /*[stem_u8_table_elems()]*/);
 bool stem_split_weights(const float *w /*[p][3][7][7]*/, const double *scale, const double *shift, int p, uint16_t *out,
                         float *init /*[64]*/);
 size_t stem_split_weights_elems();

@@ -438,6 +438,34 @@ def test_uint8_input_fused_normalise(model, variant, dev):
         model.forward_u8(x_u8.permute(0, 3, 1, 2).contiguous())          # CHW is not the contract
 
 
+@pytest.mark.parametrize("nfilter,tfilter", [(4, 8), (16, 8)])
+def test_uint8_input_other_widths(dev, nfilter, tfilter):
+    """The uint8 stem (two products, normalisation folded into the weights, border-class corrections) with one and with four
+    32-channel M-tiles (p = 32, 128): bits of the float64 oracle on the normalised tensor outside the near-tie band."""
+    from argparse import Namespace
+    from scale_imagenet_amd.spec import make_spec
+    spec = make_spec("small", nfilter, tfilter, 1)
+    st = synth.synth_state_dict(spec, calibrated=False)
+    m = ttnet.TT_vf_19lv3_imgnet_small(Namespace(nfilter=nfilter, tfilter=tfilter, layers=1, groups=[1, None, 4, None]))
+    m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in st.items()}, strict=True)
+    m = m.to(dev).eval().reserve(4)
+    u8 = synth.synth_images_u8(4)
+    # the borders carry the corrections: make them matter (bright first / last rows and columns)
+    u8[:, :, :4, :] = 255
+    u8[:, :, -4:, :] = 3
+    u8[:, :, :, :4] = 200
+    u8[:, :, :, -4:] = 17
+    xf = synth.normalize_u8(u8)
+    with torch.no_grad():
+        m.forward_u8(torch.from_numpy(np.ascontiguousarray(u8.transpose(0, 2, 3, 1))).to(dev))
+    bits = OB.unpack_rows(m.read_stage("features.3", 4), 56)
+    pre = OB.stem_pre64(xf, st)
+    bad = np.argwhere(bits != (pre >= 0).astype(np.uint8))
+    worst = max((abs(pre[tuple(d)]) for d in bad), default=0.0)
+    print(f"p = {nfilter * tfilter} uint8 stem: {len(bad)} of {bits.size} bits differ from float64, largest |pre| there {worst:.2e}")
+    assert worst < OB.NEAR_TIE
+
+
 def test_truth_table_export_from_gpu_tables(dev, tmp_path):
     """the files exported from the GPU-built table of an x-small block equal the
     files the reference's own exporter wrote (fixture from oracle/gen_golden.py)."""
