@@ -144,8 +144,9 @@ int ttnet_forward_lane(ttnet_plan *plan, int lane, const float *x_dev, int64_t n
  * uint8 image, HWC: uint8 [n][image_h][image_w][3]; the library applies ToTensor (/255) and
  * Normalize(mean, std) (utils/preprocess.py:104-108; the ImageNet constants by default,
  * ttnet_plan_set_input_norm replaces them) in front of the stem's average pool.  Same result as
- * ttnet_forward on the normalised float32 tensor up to stem near ties (the pooled value is formed
- * from the exact byte sum, rounded once).  Not available for TTNET_VALEXNET. */
+ * ttnet_forward on the normalised float32 tensor up to stem near ties (the stem works on the exact integer byte
+ * sums, with the normalisation folded into its weights: two matrix products per output instead of the three the
+ * float32 input needs).  Not available for TTNET_VALEXNET. */
 int ttnet_plan_set_input_norm(ttnet_plan *plan, const float *mean3, const float *std3);
 int ttnet_forward_u8(ttnet_plan *plan, int lane, const uint8_t *x_nhwc_dev, int64_t n, float *logits_dev, void *stream);
 
