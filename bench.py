@@ -202,7 +202,7 @@ def cpu_baseline(variant, spec, st, batch: int, budget_s: float = 8.0):
             "batches_of_%d" % small: {"value": done / el, "images": done, "seconds": round(el, 1)}}
 
 
-def roofline_records(avg_ms, models, traffic):
+def roofline_records(avg_ms, models, traffic, stem_products=3.0):
     kernels = []
     for k, ms in avg_ms.items():
         bound, units = models.get(k, ("hbm", 0.0))
@@ -238,7 +238,8 @@ def roofline_records(avg_ms, models, traffic):
         if bound == "mfma_f16x2":
             # MFMA flops the kernel really issues per algorithmic flop: 3 products of the 2-way
             # fp16 split (stem: x 8/7 for the kw 7 -> 8 padding, x 22/21 for the k-row padding)
-            issued = 3.0 * (8.0 / 7.0) * (22.0 / 21.0) if k == "stem" else 3.0
+            # (uint8 input: two products, the image's byte sums are exact in fp16 -- csrc/stem.hip)
+            issued = stem_products * (8.0 / 7.0) * (22.0 / 21.0) if k == "stem" else 3.0
             rec["mfma_flops_issued_per_flop"] = round(issued, 3)
             rec["frac_issued"] = round(ach * issued / peak, 5)
         kernels.append(rec)
@@ -424,7 +425,7 @@ def main():
     if rank == 0:
         models = kernel_models(args.variant, spec, B)
         traffic, traffic_src = measured_traffic(args.variant, B)
-        kernels = roofline_records(avg_ms, models, traffic)
+        kernels = roofline_records(avg_ms, models, traffic, 2.0 if args.input == "u8" else 3.0)
         gate = gate_path_record(avg_ms, B) if args.variant == "small" else None
         dom = max(kernels, key=lambda r: r["ms"])
         roofline = {k: dom[k] for k in dom if k not in ("kernel", "ms")}
