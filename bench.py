@@ -484,6 +484,33 @@ def main():
                 del xb
                 out["gate_path"] = {"b256": gate if B == 256 else None, "b2048": gate_path_record(big, 2048)}
                 out["kernel_us_per_256_at_b2048"] = {k: round(v * 1e3 / 8.0, 2) for k, v in big.items()}
+            if extras and args.input == "f32" and R > 1:
+                # the same forward from the decoder's uint8 images (ToTensor + Normalize fused into an integer stem
+                # with two matrix products, csrc/stem.hip): what an input pipeline that hands over uint8 gets
+                u8 = synth.synth_images_u8(B, first=rank * B, hw=spec.image_hw)
+                xu0 = torch.from_numpy(np.ascontiguousarray(u8.transpose(0, 2, 3, 1))).to(dev)
+                xu = [xu0] + [xu0.roll(k, dims=0).contiguous() for k in range(1, NX)]
+
+                def ustep(i):
+                    with torch.no_grad(), torch.cuda.stream(streams[i % R]):
+                        model.forward_u8(xu[i % NX], lane=i % R)
+                for i in range(3 * R * NX):
+                    ustep(i)
+                ks = 200
+                rates = []
+                for _ in range(3):
+                    fence()
+                    t0 = time.perf_counter()
+                    for i in range(ks):
+                        ustep(i)
+                    fence()
+                    rates.append(ks * B / (time.perf_counter() - t0))
+                rates.sort()
+                out["uint8_input"] = {"value": round(rates[1], 2), "unit": "images/s", "ms_per_step": round(1e3 * B / rates[1], 4),
+                                      "inflight": R, "input": "uint8 NHWC (ttnet_forward_u8)",
+                                      "note": "median of three windows of 200 steps; not the headline: the reference's API takes the "
+                                              "normalised float32 tensor"}
+                del xu, xu0
             if world == 1 and not args.no_extras:
                 out["parity"] = golden_parity(args.variant, spec, model, dev)
             if args.variant == "full" and os.environ.get("TTNET_FULL_EXACT") != "1":
