@@ -8,7 +8,7 @@
 // uint8 (Pillow, src/libImaging/Resample.c: precompute_coeffs, normalize_coeffs_8bpc,
 // ImagingResampleHorizontal_8bpc / Vertical_8bpc).  This file restates that arithmetic exactly
 // (integer for integer); the coefficient tables are built on the host in float64 like Pillow's, the
-// two passes run as kernels that compute only what the centre crop keeps.
+// two passes run in one kernel that computes only what the centre crop keeps (the intermediate image lives in LDS).
 //
 // Parity: pinned to Pillow 12.x -- tests/golden/ref_resize.npz holds Pillow's own outputs for seeded images of
 // nine geometries (oracle/gen_golden.py resize, run in the build container where Pillow imports) and
@@ -16,6 +16,8 @@
 // its output-size and crop-offset rules are restated.
 
 #include <math.h>
+
+#include <algorithm>
 
 #include <mutex>
 #include <vector>
@@ -69,43 +71,123 @@ Coeffs precompute(int in_size, int out_size) {
   return c;
 }
 
-__device__ inline uint8_t clip8(int v) {
-  v >>= kPrecisionBits;
-  return (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v));
+// clip8 of Resample.c: (v >> 22) saturated to 0..255.  Written as clamp-then-shift: from the shift-then-clamp form hipcc 7.2
+// selects gfx950's v_ashr_pk_u8_i32 for two of the four bytes of a packed dword and ORs the other two into the upper half of its
+// result, which is not zero there -- bytes 2 and 3 of some dwords came out wrong (tests/test_gpu_preprocess.py caught it).
+__device__ inline uint32_t clip8(int v) {
+  const int hi = (256 << kPrecisionBits) - 1;
+  v = v < 0 ? 0 : (v > hi ? hi : v);
+  return (uint32_t)v >> kPrecisionBits;
 }
 
-// horizontal pass: rows [row0, row0 + rows) of the input, output columns [x0, x0 + cols) of the resized width
-__global__ void resample_h_kernel(const uint8_t *__restrict__ src, uint8_t *__restrict__ mid, const int *__restrict__ bounds,
-                                  const int *__restrict__ kk, int ksize, int n, int h, int w, int row0, int rows, int x0, int cols) {
-  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= (size_t)n * rows * cols * 3) return;
-  const int ch = (int)(t % 3), xc = (int)((t / 3) % cols), r = (int)((t / (3 * (size_t)cols)) % rows), im = (int)(t / (3 * (size_t)cols * rows));
-  const int xx = x0 + xc, xmin = bounds[2 * xx], cnt = bounds[2 * xx + 1];
-  const uint8_t *in = src + (((size_t)im * h + row0 + r) * w + xmin) * 3 + ch;
-  const int *k = kk + (size_t)xx * ksize;
-  int ss = 1 << (kPrecisionBits - 1);
-  for (int x = 0; x < cnt; ++x) ss += (int)in[(size_t)x * 3] * k[x];
-  mid[t] = clip8(ss);
-}
-// vertical pass over the intermediate rows: output rows [y0, y0 + crop) of the resized height
-__global__ void resample_v_kernel(const uint8_t *__restrict__ mid, uint8_t *__restrict__ dst, const int *__restrict__ bounds,
-                                  const int *__restrict__ kk, int ksize, int n, int row0, int rows, int cols, int y0, int crop_h) {
-  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= (size_t)n * crop_h * cols * 3) return;
-  const int e = (int)(t % (3 * (size_t)cols)), yc = (int)((t / (3 * (size_t)cols)) % crop_h), im = (int)(t / (3 * (size_t)cols * crop_h));
-  const int yy = y0 + yc, ymin = bounds[2 * yy], cnt = bounds[2 * yy + 1];
-  const uint8_t *in = mid + ((size_t)im * rows + (ymin - row0)) * cols * 3 + e;
-  const int *k = kk + (size_t)yy * ksize;
-  int ss = 1 << (kPrecisionBits - 1);
-  for (int y = 0; y < cnt; ++y) ss += (int)in[(size_t)y * cols * 3] * k[y];
-  dst[t] = clip8(ss);
-}
-__global__ void crop_only_kernel(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, int n, int h, int w, int y0, int x0,
-                                 int crop) {
-  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= (size_t)n * crop * crop * 3) return;
-  const int e = (int)(t % (3 * (size_t)crop)), yc = (int)((t / (3 * (size_t)crop)) % crop), im = (int)(t / (3 * (size_t)crop * crop));
-  dst[t] = src[(((size_t)im * h + y0 + yc) * w + x0) * 3 + e];
+// One launch for both passes (round 3).  A workgroup makes TY output rows of one image: it stages the input rows those rows
+// depend on, chunk by chunk, as 16-byte pieces in LDS (only the columns the kept output columns depend on; a thread's loads of a
+// chunk are issued together), runs the horizontal pass of a chunk into an LDS image of the intermediate rows -- rounded to
+// uint8 exactly as Pillow stores its intermediate image -- and then the vertical pass from that image, four output bytes per
+// thread and store.  Both passes loop over the table's tap count (uniform; coefficients beyond a window's own count are zero)
+// with the four bytes of a dword side by side, so that eight LDS reads are in flight per step.  Input bytes are read once (plus
+// the few rows two neighbouring tiles share), the intermediate image never leaves the chip, nothing is allocated or waited for
+// on the host: the call is asynchronous on its stream.  (Round 2: two kernels with a byte per thread, a hipMalloc'ed
+// intermediate image, a table upload and a stream synchronisation per call: 615 us for 256 images of 375 x 500; now see
+// tools/preproc_bench.py.)
+constexpr int RS_TY = 16, RS_CHUNK = 16, RS_THREADS = 256, RS_STAGE_LOADS = 6;      // (a chunk: at most RS_CHUNK rows and RS_STAGE_LOADS x RS_THREADS pieces)
+struct ResizeArgs {
+  const uint8_t *src;
+  uint8_t *dst;
+  const int *bh, *kh, *bv, *kv;      // bounds [out][2] and coefficients [out][ksize] of the two passes (device)
+  int n, h, w, crop, x0, y0, ksh, ksv;
+  int c0, cw;                        // first input column and number of input columns the kept output columns depend on
+  int rmax;                          // most intermediate rows a tile needs
+  int row_q;                         // 16-byte pieces per staged input row (cw * 3 bytes + alignment slack)
+  int chunk;                         // input rows staged at a time
+};
+__global__ __launch_bounds__(RS_THREADS) void resize_crop_kernel(ResizeArgs a) {
+  extern __shared__ __align__(16) uint8_t lds[];
+  const int im = blockIdx.y, ty = blockIdx.x, tid = threadIdx.x;
+  const int ow = a.crop * 3, owq = ow >> 2;                // bytes / dwords per output (and intermediate) row
+  const float inv_owq = 1.0f / (float)owq, inv_rowq = 1.0f / (float)a.row_q;
+  const int ya = a.y0 + ty * RS_TY, rows_out = min(RS_TY, a.crop - ty * RS_TY);
+  const int r0 = a.bv[2 * ya], rend = a.bv[2 * (ya + rows_out - 1)] + a.bv[2 * (ya + rows_out - 1) + 1], R = rend - r0;
+  // LDS: [staged input chunk (16-byte aligned)][intermediate rows][tables of both passes]
+  uint4 *s_in = (uint4 *)lds;                                                  // [chunk][row_q]
+  uint8_t *s_mid = lds + (size_t)a.chunk * a.row_q * 16;                      // [rmax][ow]
+  int *s_bh = (int *)(s_mid + (size_t)a.rmax * ow);                            // [crop][2]  (ow % 4 == 0)
+  int *s_kh = s_bh + 2 * a.crop;                                               // [crop][ksh]
+  int *s_bv = s_kh + a.crop * a.ksh;                                           // [RS_TY][2]
+  int *s_kv = s_bv + 2 * RS_TY;                                                // [RS_TY][ksv]
+  for (int i = tid; i < 2 * a.crop; i += RS_THREADS) s_bh[i] = a.bh[2 * a.x0 + i] - ((i & 1) ? 0 : a.c0);
+  for (int i = tid; i < a.crop * a.ksh; i += RS_THREADS) s_kh[i] = a.kh[(size_t)a.x0 * a.ksh + i];
+  for (int i = tid; i < 2 * rows_out; i += RS_THREADS) s_bv[i] = a.bv[2 * ya + i] - ((i & 1) ? 0 : r0);
+  for (int i = tid; i < rows_out * a.ksv; i += RS_THREADS) s_kv[i] = a.kv[(size_t)ya * a.ksv + i];
+  const size_t total = (size_t)a.n * a.h * a.w * 3, whole_q = total >> 4;
+  for (int rc = 0; rc < R; rc += a.chunk) {
+    const int nr = min(a.chunk, R - rc);
+    __syncthreads();                                       // the previous chunk has been consumed (and the tables are in place)
+    // stage: 16-byte pieces from the piece that holds byte (row, c0); all of a thread's loads first
+    uint4 v[RS_STAGE_LOADS];
+#pragma unroll
+    for (int u = 0; u < RS_STAGE_LOADS; ++u) {
+      const int i = tid + RS_THREADS * u;
+      v[u] = make_uint4(0u, 0u, 0u, 0u);
+      if (i < nr * a.row_q) {
+        const int rr = (int)(((float)i + 0.5f) * inv_rowq), d = i - rr * a.row_q;
+        const size_t first = (((size_t)im * a.h + r0 + rc + rr) * a.w + a.c0) * 3;           // byte address of (row, c0, channel 0)
+        const size_t q = (first >> 4) + d;
+        if (q < whole_q) v[u] = ((const uint4 *)a.src)[q];
+        else if (q == whole_q) {                            // (never a byte beyond the buffer: its last, partial piece byte by byte)
+          uint32_t t[4] = {0u, 0u, 0u, 0u};
+          for (size_t b = 16 * whole_q; b < total; ++b) t[(b & 15) >> 2] |= (uint32_t)a.src[b] << (8 * (b & 3));
+          v[u] = make_uint4(t[0], t[1], t[2], t[3]);
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < RS_STAGE_LOADS; ++u) {
+      const int i = tid + RS_THREADS * u;
+      if (i < nr * a.row_q) s_in[i] = v[u];
+    }
+    __syncthreads();
+    // horizontal pass: four consecutive intermediate bytes per thread and step, the taps side by side
+    for (int i = tid; i < nr * owq; i += RS_THREADS) {
+      const int rr = (int)(((float)i + 0.5f) * inv_owq), q = i - rr * owq;
+      const size_t first = (((size_t)im * a.h + r0 + rc + rr) * a.w + a.c0) * 3;
+      const uint8_t *row = (const uint8_t *)(s_in + (size_t)rr * a.row_q) + (first & 15);
+      const int e0 = 4 * q, c_0 = e0 / 3, c_1 = (e0 + 1) / 3, c_2 = (e0 + 2) / 3, c_3 = (e0 + 3) / 3;
+      const int xb0 = s_bh[2 * c_0] * 3 + (e0 - 3 * c_0), xb1 = s_bh[2 * c_1] * 3 + (e0 + 1 - 3 * c_1);
+      const int xb2 = s_bh[2 * c_2] * 3 + (e0 + 2 - 3 * c_2), xb3 = s_bh[2 * c_3] * 3 + (e0 + 3 - 3 * c_3);
+      const int *k0 = s_kh + c_0 * a.ksh, *k1 = s_kh + c_1 * a.ksh, *k2 = s_kh + c_2 * a.ksh, *k3 = s_kh + c_3 * a.ksh;
+      const int last = a.cw * 3 - 1;                       // (taps beyond a window's own count carry a zero coefficient: any staged byte will do)
+      int a0 = 1 << (kPrecisionBits - 1), a1 = a0, a2 = a0, a3 = a0;
+#pragma nounroll
+      for (int x = 0; x < a.ksh; ++x) {
+        a0 += (int)row[min(xb0 + 3 * x, last)] * k0[x];
+        a1 += (int)row[min(xb1 + 3 * x, last)] * k1[x];
+        a2 += (int)row[min(xb2 + 3 * x, last)] * k2[x];
+        a3 += (int)row[min(xb3 + 3 * x, last)] * k3[x];
+      }
+      ((uint32_t *)(s_mid + (size_t)(rc + rr) * ow))[q] =
+          (uint32_t)clip8(a0) | ((uint32_t)clip8(a1) << 8) | ((uint32_t)clip8(a2) << 16) | ((uint32_t)clip8(a3) << 24);
+    }
+  }
+  __syncthreads();
+  // vertical pass: four consecutive output bytes per thread, one dword store
+  for (int i = tid; i < rows_out * owq; i += RS_THREADS) {
+    const int yc = (int)(((float)i + 0.5f) * inv_owq), q = i - yc * owq;
+    const int ymin = s_bv[2 * yc];
+    const int *k = s_kv + yc * a.ksv;
+    int s0 = 1 << (kPrecisionBits - 1), s1 = s0, s2 = s0, s3 = s0;
+#pragma nounroll
+    for (int y = 0; y < a.ksv; ++y) {
+      const uint32_t v = ((const uint32_t *)(s_mid + (size_t)min(ymin + y, R - 1) * ow))[q];
+      const int kvy = k[y];
+      s0 += (int)(v & 255u) * kvy;
+      s1 += (int)((v >> 8) & 255u) * kvy;
+      s2 += (int)((v >> 16) & 255u) * kvy;
+      s3 += (int)(v >> 24) * kvy;
+    }
+    const uint32_t word = (uint32_t)clip8(s0) | ((uint32_t)clip8(s1) << 8) | ((uint32_t)clip8(s2) << 16) | ((uint32_t)clip8(s3) << 24);
+    ((uint32_t *)(a.dst + ((size_t)im * a.crop + ty * RS_TY + yc) * ow))[q] = word;
+  }
 }
 
 int round_half_even(double v) { return (int)nearbyint(v); }     // Python's round(), default rounding mode
@@ -116,96 +198,95 @@ int round_half_even(double v) { return (int)nearbyint(v); }     // Python's roun
 
 using namespace ttnet;
 
+// Device copies of the coefficient tables, per geometry and device: built once, kept for the life of the process (a few KB each).
+namespace {
+struct ResizeGeo {
+  int *tab = nullptr;
+  size_t nb_h = 0, nk_h = 0, nb_v = 0, nk_v = 0;
+  int ksh = 0, ksv = 0, nw = 0, nh = 0, x0 = 0, y0 = 0, c0 = 0, cw = 0, rmax = 0;
+};
+std::mutex g_geo_mutex;
+std::vector<std::pair<std::vector<int>, ResizeGeo>> g_geos;      // key: device, h, w, resize, crop
+Coeffs identity(int size) {
+  Coeffs c;
+  c.ksize = 1;
+  c.bounds.resize((size_t)size * 2);
+  c.kk.assign((size_t)size, 1 << kPrecisionBits);
+  for (int i = 0; i < size; ++i) { c.bounds[2 * i] = i; c.bounds[2 * i + 1] = 1; }
+  return c;
+}
+}  // namespace
+
 extern "C" int ttnet_resize_center_crop_u8(const uint8_t *src_dev, int64_t n, int h, int w, int resize, int crop, uint8_t *dst_dev,
                                            void *stream) {
-  if (!src_dev || !dst_dev || n < 1 || h < 1 || w < 1 || resize < 1 || crop < 1 || n > (1 << 20)) {
+  if (!src_dev || !dst_dev || n < 1 || h < 1 || w < 1 || resize < 1 || crop < 1 || n > 65535) {
     set_error("resize_center_crop: bad argument");
     return TTNET_E_INVALID;
   }
-  hipStream_t s = (hipStream_t)stream;
-  // torchvision.transforms.functional.resize with an int size: the shorter side becomes `resize`,
-  // the longer one int(resize * long / short); an image whose shorter side already matches is kept
-  int nw = w, nh = h;
-  if (!((w <= h && w == resize) || (h <= w && h == resize))) {
-    if (w <= h) { nw = resize; nh = (int)((double)resize * h / w); }
-    else { nh = resize; nw = (int)((double)resize * w / h); }
+  if (((uintptr_t)src_dev & 15) || ((uintptr_t)dst_dev & 3) || (crop * 3) % 4) {
+    set_error("resize_center_crop: the input must be 16-byte aligned, the output 4-byte aligned and crop * 3 a multiple of 4");
+    return TTNET_E_INVALID;
   }
-  if (nw < crop || nh < crop) {
-    set_error("resize_center_crop: %dx%d resized to %dx%d is smaller than the %d crop (torchvision would pad)", w, h, nw, nh, crop);
+  hipStream_t s = (hipStream_t)stream;
+  int dev = 0;
+  TT_HIP(hipGetDevice(&dev));
+  ResizeGeo g;
+  {
+    std::lock_guard<std::mutex> lock(g_geo_mutex);
+    const std::vector<int> key = {dev, h, w, resize, crop};
+    bool found = false;
+    for (auto &kv : g_geos)
+      if (kv.first == key) { g = kv.second; found = true; break; }
+    if (!found) {
+      // torchvision.transforms.functional.resize with an int size: the shorter side becomes `resize`,
+      // the longer one int(resize * long / short); an image whose shorter side already matches is kept
+      int nw = w, nh = h;
+      if (!((w <= h && w == resize) || (h <= w && h == resize))) {
+        if (w <= h) { nw = resize; nh = (int)((double)resize * h / w); }
+        else { nh = resize; nw = (int)((double)resize * w / h); }
+      }
+      if (nw < crop || nh < crop) {
+        set_error("resize_center_crop: %dx%d resized to %dx%d is smaller than the %d crop (torchvision would pad)", w, h, nw, nh, crop);
+        return TTNET_E_UNSUPPORTED;
+      }
+      // CenterCrop: int(round((H - crop) / 2.0)); a pass Pillow skips (size unchanged) is the identity table: the same bytes
+      g.nw = nw; g.nh = nh;
+      g.y0 = round_half_even((nh - crop) / 2.0);
+      g.x0 = round_half_even((nw - crop) / 2.0);
+      const Coeffs ch = nw != w ? precompute(w, nw) : identity(w), cv = nh != h ? precompute(h, nh) : identity(h);
+      g.ksh = ch.ksize; g.ksv = cv.ksize;
+      g.c0 = ch.bounds[2 * g.x0];
+      g.cw = ch.bounds[2 * (g.x0 + crop - 1)] + ch.bounds[2 * (g.x0 + crop - 1) + 1] - g.c0;
+      for (int t0 = 0; t0 < crop; t0 += RS_TY) {
+        const int last = g.y0 + std::min(crop, t0 + RS_TY) - 1;
+        g.rmax = std::max(g.rmax, cv.bounds[2 * last] + cv.bounds[2 * last + 1] - cv.bounds[2 * (g.y0 + t0)]);
+      }
+      g.nb_h = ch.bounds.size(); g.nk_h = ch.kk.size(); g.nb_v = cv.bounds.size(); g.nk_v = cv.kk.size();
+      std::vector<int> host(g.nb_h + g.nk_h + g.nb_v + g.nk_v);
+      std::copy(ch.bounds.begin(), ch.bounds.end(), host.begin());
+      std::copy(ch.kk.begin(), ch.kk.end(), host.begin() + g.nb_h);
+      std::copy(cv.bounds.begin(), cv.bounds.end(), host.begin() + g.nb_h + g.nk_h);
+      std::copy(cv.kk.begin(), cv.kk.end(), host.begin() + g.nb_h + g.nk_h + g.nb_v);
+      TT_HIP(hipMalloc((void **)&g.tab, host.size() * sizeof(int)));
+      TT_HIP(hipMemcpy(g.tab, host.data(), host.size() * sizeof(int), hipMemcpyHostToDevice));      // (synchronous: once per geometry)
+      g_geos.emplace_back(key, g);
+    }
+  }
+  ResizeArgs a{};
+  a.src = src_dev; a.dst = dst_dev;
+  a.bh = g.tab; a.kh = g.tab + g.nb_h; a.bv = g.tab + g.nb_h + g.nk_h; a.kv = g.tab + g.nb_h + g.nk_h + g.nb_v;
+  a.n = (int)n; a.h = h; a.w = w; a.crop = crop; a.x0 = g.x0; a.y0 = g.y0; a.ksh = g.ksh; a.ksv = g.ksv;
+  a.c0 = g.c0; a.cw = g.cw; a.rmax = g.rmax;
+  a.row_q = (g.cw * 3 + 15 + 15) / 16;                    // cw * 3 bytes starting up to 15 bytes into the first piece
+  a.chunk = std::min(RS_CHUNK, (RS_STAGE_LOADS * RS_THREADS) / a.row_q);
+  const size_t lds = (size_t)a.chunk * a.row_q * 16 + (size_t)g.rmax * crop * 3 +
+                     (size_t)(2 * crop + crop * g.ksh + 2 * RS_TY + RS_TY * g.ksv) * sizeof(int);
+  if (lds > 160 * 1024 || a.chunk < 1) {
+    set_error("resize_center_crop: %dx%d -> crop %d needs %zu bytes of LDS per workgroup", w, h, crop, lds);
     return TTNET_E_UNSUPPORTED;
   }
-  // CenterCrop: int(round((H - crop) / 2.0))
-  const int y0 = round_half_even((nh - crop) / 2.0), x0 = round_half_even((nw - crop) / 2.0);
-  const bool need_h = nw != w, need_v = nh != h;
-  if (!need_h && !need_v) {
-    const size_t t = (size_t)n * crop * crop * 3;
-    hipLaunchKernelGGL(crop_only_kernel, dim3((unsigned)((t + 255) / 256)), dim3(256), 0, s, src_dev, dst_dev, (int)n, h, w, y0, x0, crop);
-    TT_HIP(hipGetLastError());
-    return TTNET_OK;
-  }
-  const Coeffs ch = precompute(w, nw), cv = precompute(h, nh);
-  // input rows the kept output rows depend on
-  int row0 = 0, rows = h;
-  if (need_v) {
-    row0 = cv.bounds[2 * y0];
-    const int last = y0 + crop - 1;
-    rows = cv.bounds[2 * last] + cv.bounds[2 * last + 1] - row0;
-  } else {
-    row0 = y0;
-    rows = crop;
-  }
-  int *d_tab = nullptr;
-  const size_t nb_h = ch.bounds.size(), nk_h = ch.kk.size(), nb_v = cv.bounds.size(), nk_v = cv.kk.size();
-  std::vector<int> host(nb_h + nk_h + nb_v + nk_v);
-  std::copy(ch.bounds.begin(), ch.bounds.end(), host.begin());
-  std::copy(ch.kk.begin(), ch.kk.end(), host.begin() + nb_h);
-  std::copy(cv.bounds.begin(), cv.bounds.end(), host.begin() + nb_h + nk_h);
-  std::copy(cv.kk.begin(), cv.kk.end(), host.begin() + nb_h + nk_h + nb_v);
-  uint8_t *mid = nullptr;
-  const size_t mid_bytes = (size_t)n * rows * crop * 3;
-  TT_HIP(hipMalloc((void **)&d_tab, host.size() * sizeof(int)));
-  if (hipMalloc((void **)&mid, mid_bytes) != hipSuccess) {
-    (void)hipFree(d_tab);
-    set_error("resize_center_crop: hipMalloc(%zu) failed", mid_bytes);
-    return TTNET_E_NOMEM;
-  }
-  int st = TTNET_OK;
-  do {
-    if (hipMemcpyAsync(d_tab, host.data(), host.size() * sizeof(int), hipMemcpyHostToDevice, s) != hipSuccess) { st = TTNET_E_HIP; break; }
-    const int *bh = d_tab, *kh = d_tab + nb_h, *bv = d_tab + nb_h + nk_h, *kv = d_tab + nb_h + nk_h + nb_v;
-    const uint8_t *vin = mid;
-    if (need_h) {
-      const size_t t = (size_t)n * rows * crop * 3;
-      hipLaunchKernelGGL(resample_h_kernel, dim3((unsigned)((t + 255) / 256)), dim3(256), 0, s, src_dev, mid, bh, kh, ch.ksize, (int)n, h, w,
-                         row0, rows, x0, crop);
-    } else {            // only a vertical pass: gather the kept columns of the needed rows
-      const size_t t = (size_t)n * rows * crop * 3;
-      // (rows x crop window at (row0, x0): crop_only_kernel with a rectangular window = two calls' worth of
-      // index arithmetic; the horizontal kernel with identity coefficients would round the same bytes)
-      std::vector<int> idb((size_t)nw * 2), idk((size_t)nw, 1 << kPrecisionBits);
-      for (int i = 0; i < nw; ++i) { idb[2 * i] = i; idb[2 * i + 1] = 1; }
-      int *d_id = nullptr;
-      if (hipMalloc((void **)&d_id, (idb.size() + idk.size()) * sizeof(int)) != hipSuccess) { st = TTNET_E_NOMEM; break; }
-      (void)hipMemcpyAsync(d_id, idb.data(), idb.size() * sizeof(int), hipMemcpyHostToDevice, s);
-      (void)hipMemcpyAsync(d_id + idb.size(), idk.data(), idk.size() * sizeof(int), hipMemcpyHostToDevice, s);
-      hipLaunchKernelGGL(resample_h_kernel, dim3((unsigned)((t + 255) / 256)), dim3(256), 0, s, src_dev, mid, d_id, d_id + idb.size(), 1,
-                         (int)n, h, w, row0, rows, x0, crop);
-      (void)hipStreamSynchronize(s);
-      (void)hipFree(d_id);
-    }
-    if (need_v) {
-      const size_t t = (size_t)n * crop * crop * 3;
-      hipLaunchKernelGGL(resample_v_kernel, dim3((unsigned)((t + 255) / 256)), dim3(256), 0, s, vin, dst_dev, bv, kv, cv.ksize, (int)n, row0,
-                         rows, crop, y0, crop);
-    } else {
-      if (hipMemcpyAsync(dst_dev, mid, mid_bytes, hipMemcpyDeviceToDevice, s) != hipSuccess) { st = TTNET_E_HIP; break; }
-    }
-    if (hipGetLastError() != hipSuccess) { st = TTNET_E_HIP; break; }
-  } while (0);
-  // the tables and the intermediate image are freed once the stream has consumed them
-  (void)hipStreamSynchronize(s);
-  (void)hipFree(mid);
-  (void)hipFree(d_tab);
-  if (st != TTNET_OK) set_error("resize_center_crop: a HIP call failed");
-  return st;
+  TT_TRY(ensure_dynamic_lds((const void *)resize_crop_kernel, lds));
+  hipLaunchKernelGGL(resize_crop_kernel, dim3((crop + RS_TY - 1) / RS_TY, (unsigned)n), dim3(RS_THREADS), lds, s, a);
+  TT_HIP(hipGetLastError());
+  return TTNET_OK;
 }
