@@ -101,27 +101,34 @@ struct ResizeArgs {
   int row_q;                         // 16-byte pieces per staged input row (cw * 3 bytes + alignment slack)
   int chunk;                         // input rows staged at a time
 };
+// KSH / KSV: the tap counts of the two tables when they are one of 1, 3, 5, 7, 9 (the loops unroll and the byte reads of a
+// window get immediate offsets); 0 = any count, at run time.
+template <int KSH, int KSV>
 __global__ __launch_bounds__(RS_THREADS) void resize_crop_kernel(ResizeArgs a) {
   extern __shared__ __align__(16) uint8_t lds[];
   const int im = blockIdx.y, ty = blockIdx.x, tid = threadIdx.x;
+  const int ksh = KSH ? KSH : a.ksh, ksv = KSV ? KSV : a.ksv;
   const int ow = a.crop * 3, owq = ow >> 2;                // bytes / dwords per output (and intermediate) row
-  const float inv_owq = 1.0f / (float)owq, inv_rowq = 1.0f / (float)a.row_q;
+  const float inv_owq = 1.0f / (float)owq, inv_rowq = 1.0f / (float)a.row_q, inv_crop = 1.0f / (float)a.crop;
   const int ya = a.y0 + ty * RS_TY, rows_out = min(RS_TY, a.crop - ty * RS_TY);
   const int r0 = a.bv[2 * ya], rend = a.bv[2 * (ya + rows_out - 1)] + a.bv[2 * (ya + rows_out - 1) + 1], R = rend - r0;
   // LDS: [staged input chunk (16-byte aligned)][intermediate rows][tables of both passes]
   uint4 *s_in = (uint4 *)lds;                                                  // [chunk][row_q]
-  uint8_t *s_mid = lds + (size_t)a.chunk * a.row_q * 16;                      // [rmax][ow]
-  int *s_bh = (int *)(s_mid + (size_t)a.rmax * ow);                            // [crop][2]  (ow % 4 == 0)
-  int *s_kh = s_bh + 2 * a.crop;                                               // [crop][ksh]
-  int *s_bv = s_kh + a.crop * a.ksh;                                           // [RS_TY][2]
-  int *s_kv = s_bv + 2 * RS_TY;                                                // [RS_TY][ksv]
-  for (int i = tid; i < 2 * a.crop; i += RS_THREADS) s_bh[i] = a.bh[2 * a.x0 + i] - ((i & 1) ? 0 : a.c0);
-  for (int i = tid; i < a.crop * a.ksh; i += RS_THREADS) s_kh[i] = a.kh[(size_t)a.x0 * a.ksh + i];
-  for (int i = tid; i < 2 * rows_out; i += RS_THREADS) s_bv[i] = a.bv[2 * ya + i] - ((i & 1) ? 0 : r0);
-  for (int i = tid; i < rows_out * a.ksv; i += RS_THREADS) s_kv[i] = a.kv[(size_t)ya * a.ksv + i];
+  uint8_t *s_mid = lds + (size_t)a.chunk * a.row_q * 16;                       // [rmax][ow]
+  int *s_xb = (int *)(s_mid + (size_t)a.rmax * ow);                            // [crop] byte offset of a window's first tap  (ow % 4 == 0)
+  int *s_kh = s_xb + a.crop;                                                   // [crop][ksh]
+  int *s_bv = s_kh + a.crop * ksh;                                             // [RS_TY] first intermediate row of a window
+  int *s_kv = s_bv + RS_TY;                                                    // [RS_TY][ksv]
+  for (int i = tid; i < a.crop; i += RS_THREADS) s_xb[i] = (a.bh[2 * (a.x0 + i)] - a.c0) * 3;
+  for (int i = tid; i < a.crop * ksh; i += RS_THREADS) s_kh[i] = a.kh[(size_t)a.x0 * ksh + i];
+  for (int i = tid; i < rows_out; i += RS_THREADS) s_bv[i] = a.bv[2 * (ya + i)] - r0;
+  for (int i = tid; i < rows_out * ksv; i += RS_THREADS) s_kv[i] = a.kv[(size_t)ya * ksv + i];
   const size_t total = (size_t)a.n * a.h * a.w * 3, whole_q = total >> 4;
+  const uint32_t pitch = (uint32_t)a.w * 3u;               // bytes per input row
   for (int rc = 0; rc < R; rc += a.chunk) {
     const int nr = min(a.chunk, R - rc);
+    const size_t first0 = (((size_t)im * a.h + r0 + rc) * a.w + a.c0) * 3;                   // byte address of (first row of the chunk, c0, channel 0)
+    const uint32_t al0 = (uint32_t)(first0 & 15);
     __syncthreads();                                       // the previous chunk has been consumed (and the tables are in place)
     // stage: 16-byte pieces from the piece that holds byte (row, c0); all of a thread's loads first
     uint4 v[RS_STAGE_LOADS];
@@ -131,8 +138,7 @@ __global__ __launch_bounds__(RS_THREADS) void resize_crop_kernel(ResizeArgs a) {
       v[u] = make_uint4(0u, 0u, 0u, 0u);
       if (i < nr * a.row_q) {
         const int rr = (int)(((float)i + 0.5f) * inv_rowq), d = i - rr * a.row_q;
-        const size_t first = (((size_t)im * a.h + r0 + rc + rr) * a.w + a.c0) * 3;           // byte address of (row, c0, channel 0)
-        const size_t q = (first >> 4) + d;
+        const size_t q = ((first0 + (size_t)((uint32_t)rr * pitch)) >> 4) + d;
         if (q < whole_q) v[u] = ((const uint4 *)a.src)[q];
         else if (q == whole_q) {                            // (never a byte beyond the buffer: its last, partial piece byte by byte)
           uint32_t t[4] = {0u, 0u, 0u, 0u};
@@ -147,45 +153,60 @@ __global__ __launch_bounds__(RS_THREADS) void resize_crop_kernel(ResizeArgs a) {
       if (i < nr * a.row_q) s_in[i] = v[u];
     }
     __syncthreads();
-    // horizontal pass: four consecutive intermediate bytes per thread and step, the taps side by side
-    for (int i = tid; i < nr * owq; i += RS_THREADS) {
-      const int rr = (int)(((float)i + 0.5f) * inv_owq), q = i - rr * owq;
-      const size_t first = (((size_t)im * a.h + r0 + rc + rr) * a.w + a.c0) * 3;
-      const uint8_t *row = (const uint8_t *)(s_in + (size_t)rr * a.row_q) + (first & 15);
-      const int e0 = 4 * q, c_0 = e0 / 3, c_1 = (e0 + 1) / 3, c_2 = (e0 + 2) / 3, c_3 = (e0 + 3) / 3;
-      const int xb0 = s_bh[2 * c_0] * 3 + (e0 - 3 * c_0), xb1 = s_bh[2 * c_1] * 3 + (e0 + 1 - 3 * c_1);
-      const int xb2 = s_bh[2 * c_2] * 3 + (e0 + 2 - 3 * c_2), xb3 = s_bh[2 * c_3] * 3 + (e0 + 3 - 3 * c_3);
-      const int *k0 = s_kh + c_0 * a.ksh, *k1 = s_kh + c_1 * a.ksh, *k2 = s_kh + c_2 * a.ksh, *k3 = s_kh + c_3 * a.ksh;
-      const int last = a.cw * 3 - 1;                       // (taps beyond a window's own count carry a zero coefficient: any staged byte will do)
-      int a0 = 1 << (kPrecisionBits - 1), a1 = a0, a2 = a0, a3 = a0;
+    // horizontal pass: one intermediate pixel (three bytes) per thread and step.  Taps beyond a window's own count carry a
+    // zero coefficient, and what they read still lies inside the LDS allocation (the staged chunk is followed by s_mid).
+    for (int i = tid; i < nr * a.crop; i += RS_THREADS) {
+      const int rr = (int)(((float)i + 0.5f) * inv_crop), xc = i - rr * a.crop;
+      const uint8_t *p = (const uint8_t *)s_in + (uint32_t)rr * (uint32_t)(a.row_q * 16) + ((al0 + (uint32_t)rr * pitch) & 15u) + s_xb[xc];
+      const int *k = s_kh + xc * ksh;
+      int a0 = 1 << (kPrecisionBits - 1), a1 = a0, a2 = a0;
+      // (24-bit multiplies: a byte times a coefficient below 2^23 -- the full-rate v_mad_i32_i24, not the quarter-rate 32-bit one)
+      if constexpr (KSH != 0) {
+#pragma unroll
+        for (int x = 0; x < KSH; ++x) {
+          const int kx = k[x];
+          a0 += __mul24((int)p[3 * x], kx);
+          a1 += __mul24((int)p[3 * x + 1], kx);
+          a2 += __mul24((int)p[3 * x + 2], kx);
+        }
+      } else {
 #pragma nounroll
-      for (int x = 0; x < a.ksh; ++x) {
-        a0 += (int)row[min(xb0 + 3 * x, last)] * k0[x];
-        a1 += (int)row[min(xb1 + 3 * x, last)] * k1[x];
-        a2 += (int)row[min(xb2 + 3 * x, last)] * k2[x];
-        a3 += (int)row[min(xb3 + 3 * x, last)] * k3[x];
+        for (int x = 0; x < ksh; ++x) {
+          const int kx = k[x];
+          a0 += __mul24((int)p[3 * x], kx);
+          a1 += __mul24((int)p[3 * x + 1], kx);
+          a2 += __mul24((int)p[3 * x + 2], kx);
+        }
       }
-      ((uint32_t *)(s_mid + (size_t)(rc + rr) * ow))[q] =
-          (uint32_t)clip8(a0) | ((uint32_t)clip8(a1) << 8) | ((uint32_t)clip8(a2) << 16) | ((uint32_t)clip8(a3) << 24);
+      uint8_t *o = s_mid + (size_t)(rc + rr) * ow + 3 * xc;
+      o[0] = (uint8_t)clip8(a0);
+      o[1] = (uint8_t)clip8(a1);
+      o[2] = (uint8_t)clip8(a2);
     }
   }
   __syncthreads();
   // vertical pass: four consecutive output bytes per thread, one dword store
   for (int i = tid; i < rows_out * owq; i += RS_THREADS) {
     const int yc = (int)(((float)i + 0.5f) * inv_owq), q = i - yc * owq;
-    const int ymin = s_bv[2 * yc];
-    const int *k = s_kv + yc * a.ksv;
+    const int ymin = s_bv[yc];
+    const int *k = s_kv + yc * ksv;
     int s0 = 1 << (kPrecisionBits - 1), s1 = s0, s2 = s0, s3 = s0;
-#pragma nounroll
-    for (int y = 0; y < a.ksv; ++y) {
+    auto tap = [&](int y) {
       const uint32_t v = ((const uint32_t *)(s_mid + (size_t)min(ymin + y, R - 1) * ow))[q];
       const int kvy = k[y];
-      s0 += (int)(v & 255u) * kvy;
-      s1 += (int)((v >> 8) & 255u) * kvy;
-      s2 += (int)((v >> 16) & 255u) * kvy;
-      s3 += (int)(v >> 24) * kvy;
+      s0 += __mul24((int)(v & 255u), kvy);
+      s1 += __mul24((int)((v >> 8) & 255u), kvy);
+      s2 += __mul24((int)((v >> 16) & 255u), kvy);
+      s3 += __mul24((int)(v >> 24), kvy);
+    };
+    if constexpr (KSV != 0) {
+#pragma unroll
+      for (int y = 0; y < KSV; ++y) tap(y);
+    } else {
+#pragma nounroll
+      for (int y = 0; y < ksv; ++y) tap(y);
     }
-    const uint32_t word = (uint32_t)clip8(s0) | ((uint32_t)clip8(s1) << 8) | ((uint32_t)clip8(s2) << 16) | ((uint32_t)clip8(s3) << 24);
+    const uint32_t word = clip8(s0) | (clip8(s1) << 8) | (clip8(s2) << 16) | (clip8(s3) << 24);
     ((uint32_t *)(a.dst + ((size_t)im * a.crop + ty * RS_TY + yc) * ow))[q] = word;
   }
 }
@@ -280,13 +301,23 @@ extern "C" int ttnet_resize_center_crop_u8(const uint8_t *src_dev, int64_t n, in
   a.row_q = (g.cw * 3 + 15 + 15) / 16;                    // cw * 3 bytes starting up to 15 bytes into the first piece
   a.chunk = std::min(RS_CHUNK, (RS_STAGE_LOADS * RS_THREADS) / a.row_q);
   const size_t lds = (size_t)a.chunk * a.row_q * 16 + (size_t)g.rmax * crop * 3 +
-                     (size_t)(2 * crop + crop * g.ksh + 2 * RS_TY + RS_TY * g.ksv) * sizeof(int);
+                     (size_t)(crop + crop * g.ksh + RS_TY + RS_TY * g.ksv) * sizeof(int);
   if (lds > 160 * 1024 || a.chunk < 1) {
     set_error("resize_center_crop: %dx%d -> crop %d needs %zu bytes of LDS per workgroup", w, h, crop, lds);
     return TTNET_E_UNSUPPORTED;
   }
-  TT_TRY(ensure_dynamic_lds((const void *)resize_crop_kernel, lds));
-  hipLaunchKernelGGL(resize_crop_kernel, dim3((crop + RS_TY - 1) / RS_TY, (unsigned)n), dim3(RS_THREADS), lds, s, a);
+  auto launch = [&](auto kernel) -> int {
+    TT_TRY(ensure_dynamic_lds((const void *)kernel, lds));
+    hipLaunchKernelGGL(kernel, dim3((crop + RS_TY - 1) / RS_TY, (unsigned)n), dim3(RS_THREADS), lds, s, a);
+    return TTNET_OK;
+  };
+  // the common pairs of tap counts get unrolled loops (the aspect is kept, so both passes have the same scale and count)
+  if (g.ksh == 1 && g.ksv == 1) TT_TRY(launch(resize_crop_kernel<1, 1>));
+  else if (g.ksh == 3 && g.ksv == 3) TT_TRY(launch(resize_crop_kernel<3, 3>));
+  else if (g.ksh == 5 && g.ksv == 5) TT_TRY(launch(resize_crop_kernel<5, 5>));
+  else if (g.ksh == 7 && g.ksv == 7) TT_TRY(launch(resize_crop_kernel<7, 7>));
+  else if (g.ksh == 9 && g.ksv == 9) TT_TRY(launch(resize_crop_kernel<9, 9>));
+  else TT_TRY(launch(resize_crop_kernel<0, 0>));
   TT_HIP(hipGetLastError());
   return TTNET_OK;
 }
