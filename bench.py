@@ -465,7 +465,7 @@ def main():
                                       "batch 256 float32" if NX > 1 else "one buffer: the input may be served from the Infinity Cache"},
             "serial": {"value": round(n_total * args.steps / elapsed_serial, 2),
                        "ms_per_step": round(1e3 * elapsed_serial / args.steps, 4),
-                       "note": "the same K steps with one batch in flight (every step waits for the previous one)"},
+                       "note": "the same K steps with one batch in flight (every step waits for the previous one), on the same plan: with lanes >= 2 its float32 stem runs on 128 CUs, which costs a forward that runs alone ~4 %"},
             "roofline": roofline,
             "roofline_kernels": kernels + ([gate] if gate else []),
             "traffic_source": traffic_src,

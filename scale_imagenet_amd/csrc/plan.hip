@@ -1089,7 +1089,7 @@ int forward_eager(ttnet_plan *pl, const void *x_dev, bool u8, int64_t n, float *
   }
   TT_TIMED(pl, "stem", s,
            launch_stem(x_dev, u8, pl->norm_tab, u8 ? pl->stem_wt_u8 : pl->stem_wt, u8 ? pl->stem_init_u8 : pl->stem_init, pl->x_rp[0], (pl->full || pl->fused || pl->xs) ? nullptr : pl->x_cp[0], (int)n,
-                       pl->p, pl->range_dev, s));
+                       pl->p, pl->range_dev, s, (pl->lanes.size() >= 2 && !u8 && !pl->full) ? 128 : 256));      // (stem.hip: half the CUs for float32 input with batches in flight)
   return run_from_blocks(pl, (int)n, logits_dev, s);
 }
 
@@ -1208,6 +1208,7 @@ int ttnet_plan_set_lanes(ttnet_plan *pl, int lanes) {
   }
   (void)hipSetDevice(pl->device);
   const int keep = pl->cur;
+  if ((int)pl->lanes.size() < lanes && pl->lanes.size() == 1) TT_TRY(invalidate_graphs(pl));      // (the stem's grid depends on lanes >= 2)
   while ((int)pl->lanes.size() < lanes) {
     // allocate a fresh workspace into the plan's pointers, file it as a new lane, restore
     pl->lanes[pl->cur].last_n = pl->last_n;

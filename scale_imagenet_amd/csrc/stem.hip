@@ -796,7 +796,7 @@ int stem_kernel_arg_sizes(const int **sizes) {
 }
 
 int launch_stem(const void *x, bool x_is_u8, const uint32_t *norm_tab, const void *wfrag, const float *init, uint64_t *rp,
-                uint16_t *cp, int n, int p, uint32_t *range_flag, hipStream_t s) {
+                uint16_t *cp, int n, int p, uint32_t *range_flag, hipStream_t s, int workgroups) {
   if (p < 1 || p > 128 || (cp && p != 64)) {
     set_error("stem: p=%d outside [1,128] (channel words need p = 64)", p);
     return TTNET_E_UNSUPPORTED;
@@ -808,8 +808,13 @@ int launch_stem(const void *x, bool x_is_u8, const uint32_t *norm_tab, const voi
   }
   const size_t lds = (size_t)2 * TILE_DW * 4 + (size_t)2 * 32 * MT * (NT + 2) * 4 + (x_is_u8 ? (size_t)16 * 32 * MT * 4 : 0);
   const int items = n * NBLK;
-  static const int grid_cap = getenv("TTNET_STEM_GRID") ? atoi(getenv("TTNET_STEM_GRID")) : 256;      // (diagnostic)
-  const int grid = std::min(items, std::max(1, grid_cap));
+  // Persistent workgroups: one per CU when a forward has the chip to itself; HALF the CUs when the plan keeps several batches in
+  // flight.  The kernel is bound by the energy of its matrix instructions, not by per-CU throughput: on 128 CUs it holds a
+  // higher clock and takes 73 - 79 us instead of 57, and the other batch's kernels run on the other 128 meanwhile -- the forward
+  // with two batches in flight gains 5 - 7 % (profiles/r03_cache_policy.txt, same-box A/B; one batch at a time would lose 4 %; the
+  // uint8 kernel, with two products, and the full variant gain nothing and keep 256: the caller decides).
+  static const int grid_env = getenv("TTNET_STEM_GRID") ? atoi(getenv("TTNET_STEM_GRID")) : 0;        // (diagnostic override)
+  const int grid = std::min(items, std::max(1, grid_env > 0 ? grid_env : (workgroups > 0 ? workgroups : 256)));
   auto launch = [&](auto kernel) -> int {
     TT_TRY(ensure_dynamic_lds((const void *)kernel, lds));
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(STEM_THREADS), lds, s, x, (const uint4 *)wfrag, init, rp, cp, p, n, norm_tab,

@@ -213,7 +213,7 @@ float weight_prescale(const float *w, size_t n);
 // stem_split_weights, which fails if the shift is out of range)
 // x: float32 NCHW, or (x_is_u8) uint8 NHWC with wfrag / init / norm_tab from stem_split_weights_u8
 int launch_stem(const void *x, bool x_is_u8, const uint32_t *norm_tab, const void *wfrag, const float *init, uint64_t *rp,
-                uint16_t *cp, int n, int p, uint32_t *range_flag, hipStream_t s);
+                uint16_t *cp, int n, int p, uint32_t *range_flag, hipStream_t s, int workgroups = 0);      // 0: one per CU
 // uint8 input: weights with the normalisation folded in, centres and border corrections (stem.hip)
 size_t stem_u8_table_elems();
 bool stem_split_weights_u8(const float *w, const double *scale, const double *shift, int p, const float mean[3], const float stdv[3],
