@@ -156,8 +156,9 @@ int ttnet_forward_u8(ttnet_plan *plan, int lane, const uint8_t *x_nhwc_dev, int6
  * Resize is torchvision's resize of a PIL image, i.e. Pillow's bilinear resampling with antialiasing in
  * 8-bit fixed point (horizontal pass, then vertical); the output size and crop offsets follow
  * torchvision.transforms.functional (shorter side -> resize, longer side int(resize * long / short);
- * offsets int(round((size - crop) / 2.0))).  Not bound to a plan.  Synchronises `stream` before returning
- * (it frees its scratch).  Byte-identical to Pillow 12.x on the committed fixture tests/golden/ref_resize.npz
+ * offsets int(round((size - crop) / 2.0))).  Not bound to a plan.  Asynchronous on `stream` (one kernel; the first call with a
+ * geometry uploads its coefficient tables synchronously and keeps them for the life of the process).  src must be 16-byte
+ * aligned, dst 4-byte aligned, crop * 3 a multiple of 4, n <= 65535.  Byte-identical to Pillow 12.x on the committed fixture tests/golden/ref_resize.npz
  * (Pillow's own outputs for seeded images of nine geometries); torchvision is not importable where this is
  * built, so its output-size and crop-offset rules are restated. */
 int ttnet_resize_center_crop_u8(const uint8_t *src_hwc_dev, int64_t n, int h, int w, int resize, int crop,
